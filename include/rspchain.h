@@ -1,0 +1,216 @@
+/*
+ * rspchain.h -- C ABI of the MI355X-native sdf-fft -> logMagMux -> CFAR path.
+ *
+ * This is the drop-in boundary: every entry point replaces one interface of the
+ * reference (milovanovic/rsp-chains, a Chisel generator; citations relative to
+ * /root/reference/).  The reference drives its chain through exactly three
+ * things -- an elaboration-time parameter object, memory-mapped register writes,
+ * and a 32-bit AXI4-Stream in / out -- and so does this library:
+ *
+ *   reference                                              this ABI
+ *   -----------------------------------------------------  -------------------------
+ *   FftMagCfarVanillaParameters(fftParams, magParams,      rsp_chain_params
+ *     cfarParams, *Address, beatBytes)                       (+ rsp_chain_default_params)
+ *     src/main/scala/FftMagCfarChain.scala:21-29,77-116
+ *   LazyModule(new FftMagCfarChainVanilla(params))         rsp_chain_create / _destroy
+ *     FftMagCfarChain.scala:31-49,119
+ *   AXI4MasterModel.memWriteWord(addr, value)              rsp_chain_write_reg / _read_reg
+ *     src/test/scala/FftMagCfarChainTester.scala:82-132
+ *   AXI4StreamModel master.addTransactions(beats, last)    rsp_chain_process (host buffers)
+ *     + peek(out.bits.data) loop, fftSize words            rsp_chain_process_device (HBM)
+ *     FftMagCfarChainTester.scala:137,145-151
+ *
+ * Plain C types only.  Return value 0 = RSP_OK, negative = error; the message
+ * is available from rsp_last_error() (thread-local).  Nothing throws across the
+ * ABI.  The caller owns every buffer it passes; the library owns the device
+ * buffers, twiddle ROMs and stream inside a handle.  A handle is not
+ * thread-safe: one handle per host thread; distinct handles may run
+ * concurrently.  There is no CPU fallback: without a HIP device
+ * rsp_chain_create fails with RSP_ERR_DEVICE.
+ */
+#ifndef RSPCHAIN_H
+#define RSPCHAIN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSP_ABI_VERSION 1
+#define RSP_MAX_STAGES 16
+
+enum {
+  RSP_OK = 0,
+  RSP_ERR_INVALID = -1,     /* a Scala `require` of the reference would have failed   */
+  RSP_ERR_UNSUPPORTED = -2, /* legal in the reference, not implemented on the GPU path */
+  RSP_ERR_DEVICE = -3,      /* no HIP device / HIP runtime error                       */
+  RSP_ERR_ADDRESS = -4,     /* register address decodes to no block (AXI DECERR)       */
+  RSP_ERR_NOMEM = -5
+};
+
+/* FixedPoint(width.W, binaryPoint.BP), e.g. FftMagCfarChain.scala:102-104 */
+typedef struct rsp_fixed_proto {
+  int32_t width;
+  int32_t binaryPoint;
+} rsp_fixed_proto;
+
+/* AddressSet(base, mask), FftMagCfarChain.scala:113-115 */
+typedef struct rsp_address_set {
+  uint32_t base;
+  uint32_t mask;
+} rsp_address_set;
+
+/* FFTParams.fixed(...), FftMagCfarChain.scala:78-90 (same field names). */
+typedef struct rsp_fft_params {
+  int32_t dataWidth;
+  int32_t twiddleWidth;
+  int32_t numPoints;
+  int32_t useBitReverse;
+  int32_t runTime;
+  int32_t numAddPipes; /* latency only: no numerical meaning on the GPU */
+  int32_t numMulPipes; /* latency only */
+  int32_t expandLogic[RSP_MAX_STAGES];
+  int32_t keepMSBorLSB[RSP_MAX_STAGES];
+  int32_t minSRAMdepth; /* area only */
+  int32_t binPoint;
+  int32_t trimType; /* build extension: RSP_TRIM_*; reference uses upstream default */
+} rsp_fft_params;
+
+/* MAGParams.fixed(...), FftMagCfarChain.scala:91-100 */
+typedef struct rsp_mag_params {
+  int32_t dataWidth;
+  int32_t binPoint;
+  int32_t dataWidthLog;
+  int32_t binPointLog;
+  int32_t log2LookUpWidth;
+  int32_t useLast;
+  int32_t numAddPipes;
+  int32_t numMulPipes;
+} rsp_mag_params;
+
+/* CFARParams(...), FftMagCfarChain.scala:101-112 */
+typedef struct rsp_cfar_params {
+  rsp_fixed_proto protoIn;
+  rsp_fixed_proto protoThreshold;
+  rsp_fixed_proto protoScaler;
+  int32_t leadLaggWindowSize;
+  int32_t guardWindowSize;
+  int32_t sendCut;
+  int32_t fftSize;
+  int32_t minSubWindowSize; /* -1 = None */
+  int32_t includeCASH;
+  int32_t CFARAlgorithm; /* RSP_ALG_CA / _GOS / _GOSCA: FftMagCfarChainTester.scala:105,110,123 */
+  int32_t numMulPipes;
+  int32_t edgeMode; /* build extension: RSP_EDGE_* */
+} rsp_cfar_params;
+
+enum { RSP_TRIM_FLOOR = 0, RSP_TRIM_HALF_UP = 1, RSP_TRIM_CONVERGENT = 2 };
+enum { RSP_ALG_CA = 0, RSP_ALG_GOS = 1, RSP_ALG_GOSCA = 2 };
+enum { RSP_EDGE_ZERO = 0, RSP_EDGE_WRAP = 1 };
+enum { RSP_MAG_SQR = 0, RSP_MAG_LOG2 = 1, RSP_MAG_JPL = 2 }; /* 2: FftMagCfarChainTester.scala:84 */
+enum { RSP_MODE_CA = 0, RSP_MODE_GO = 1, RSP_MODE_SO = 2, RSP_MODE_CASH = 3 }; /* Tester:86-92 */
+
+/* Sample type streamed through the chain.  FIXED16 is the reference's
+ * FixedPoint(16.W) data path with its 32-bit {re[31:16], im[15:0]} beat
+ * (src/test/scala/RspChainTesterUtils.scala:105-109).  F32 is the fp32 data
+ * path BASELINE.json's GPU configs ask for: a beat is one interleaved
+ * complex64 {re, im} and an output word is the fp32 threshold with its
+ * mantissa LSB replaced by the peak flag (bin index = position). */
+enum { RSP_DTYPE_FIXED16 = 0, RSP_DTYPE_F32 = 1 };
+
+/* FftMagCfarVanillaParameters, FftMagCfarChain.scala:21-29, + GPU extensions. */
+typedef struct rsp_chain_params {
+  rsp_fft_params fftParams;
+  rsp_mag_params magParams;
+  rsp_cfar_params cfarParams;
+  rsp_address_set fftAddress;
+  rsp_address_set magAddress;
+  rsp_address_set cfarAddress;
+  int32_t beatBytes;
+  /* ---- extensions with no reference counterpart ---- */
+  int32_t dtype;     /* RSP_DTYPE_* */
+  int32_t device;    /* HIP device ordinal */
+  int32_t dopplerPoints; /* 0 = 1-D chain; else slow-time FFT size of the 2-D range-Doppler chain */
+  int32_t refDoppler;    /* 2-D CFAR training / guard half-widths along Doppler */
+  int32_t guardDoppler;
+  int32_t reserved[8];
+} rsp_chain_params;
+
+typedef struct rsp_chain rsp_chain;
+
+/* One detection of the compact list (rsp_chain_detections_device). */
+typedef struct rsp_detection {
+  uint32_t frame; /* frame (1-D) or channel (2-D) index within the call        */
+  uint32_t bin;   /* range bin                                                   */
+  uint32_t doppler; /* Doppler bin (0 for the 1-D chain)                         */
+  uint32_t word;  /* the dense output word of that cell                          */
+} rsp_detection;
+
+/* --- construction --------------------------------------------------------- */
+uint32_t rsp_abi_version(void);
+const char* rsp_last_error(void);
+/* Parameters of FftMagCfarChainVanillaApp, FftMagCfarChain.scala:77-116. */
+void rsp_chain_default_params(rsp_chain_params* p);
+/* Checks what elaboration would check; usable without a device. */
+int rsp_chain_validate_params(const rsp_chain_params* p);
+int rsp_chain_create(const rsp_chain_params* p, rsp_chain** out);
+void rsp_chain_destroy(rsp_chain* c);
+
+/* --- control plane: AXI4 register file ------------------- */
+/* memWriteWord(addr, value), FftMagCfarChainTester.scala:82-132.  Register state
+ * after create = RunTimeRspChainParams() defaults
+ * (src/test/scala/RspChainVanillaTester.scala:35-48) with fftSize = numPoints. */
+int rsp_chain_write_reg(rsp_chain* c, uint32_t addr, uint32_t value);
+int rsp_chain_read_reg(rsp_chain* c, uint32_t addr, uint32_t* value);
+/* Cross-register `require`s of RunTimeRspChainParams (RspChainVanillaTester.scala:50-61)
+ * + consistency FFT stages <-> CFAR fftSize; called by process, exposed for hosts. */
+int rsp_chain_check_regs(rsp_chain* c);
+
+/* --- data plane ------------------------------------------------------------ */
+/* Stream n_frames frames of fftSize beats in (TLAST is implied on the final
+ * beat of every frame, Tester:137), collect fftSize output words per frame
+ * (Tester:145-151).  Host buffers; synchronous.  Beat = 4 bytes (FIXED16) or
+ * 8 bytes (F32).  For the 2-D chain a "frame" is one channel's
+ * dopplerPoints x fftSize map, [doppler][range] row-major. */
+int rsp_chain_process(rsp_chain* c, const void* in_beats, size_t n_frames, uint32_t* out_words);
+/* Same with buffers already resident in HBM; asynchronous on the chain's stream. */
+int rsp_chain_process_device(rsp_chain* c, const void* d_in_beats, size_t n_frames,
+                             uint32_t* d_out_words);
+/* Compact the peak cells of a dense device result into list[0..cap) (device
+ * memory); *d_count (device uint32) receives the number found (may exceed cap;
+ * only cap entries are stored).  Order within the list is unspecified. */
+int rsp_chain_detections_device(rsp_chain* c, const uint32_t* d_out_words, size_t n_frames,
+                                rsp_detection* d_list, uint32_t cap, uint32_t* d_count);
+/* Host-buffer convenience: dense process + compaction; list sorted by (frame, doppler, bin). */
+int rsp_chain_process_detections(rsp_chain* c, const void* in_beats, size_t n_frames,
+                                 rsp_detection* list, size_t cap, size_t* n_found);
+
+/* --- stream / memory / timing plumbing -------------------------------------- */
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores
+ * the chain's own stream. */
+int rsp_chain_set_stream(rsp_chain* c, void* hip_stream);
+int rsp_chain_synchronize(rsp_chain* c);
+/* hipEvent pair on the chain's stream around whatever is enqueued between the calls. */
+int rsp_chain_timer_start(rsp_chain* c);
+int rsp_chain_timer_stop(rsp_chain* c, float* elapsed_ms); /* synchronises */
+int rsp_device_count(int* n);
+int rsp_device_malloc(int device, void** ptr, size_t bytes);
+int rsp_device_free(int device, void* ptr);
+int rsp_memcpy_h2d(int device, void* dst, const void* src, size_t bytes);
+int rsp_memcpy_d2h(int device, void* dst, const void* src, size_t bytes);
+
+/* --- wire-format helpers ---------------------------------------------------- */
+/* formAXI4StreamComplexData, RspChainTesterUtils.scala:105-109 */
+uint32_t rsp_pack_iq(int32_t re, int32_t im);
+/* Tester:163-167: threshold = word >> (log2(fftSize)+1) (arithmetic), peak = word & 1 */
+void rsp_unpack_word(uint32_t word, int32_t log2_fft_size, int32_t* threshold, uint32_t* bin,
+                     uint32_t* peak);
+/* F32 output word: threshold bits with LSB cleared, peak in the LSB. */
+void rsp_unpack_word_f32(uint32_t word, float* threshold, uint32_t* peak);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

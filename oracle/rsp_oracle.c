@@ -1,0 +1,523 @@
+/*
+ * rsp_oracle.c -- CPU restatement of sdf-fft -> logMagMux -> CFAR.  See rsp_oracle.h:
+ * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (reference arithmetic is in empty,
+ * un-vendored submodules; its tests pin no numbers).
+ *
+ * Citations are relative to /root/reference/.  "Tester" =
+ * src/test/scala/FftMagCfarChainTester.scala, "Utils" =
+ * src/test/scala/RspChainTesterUtils.scala, "Chain" =
+ * src/main/scala/FftMagCfarChain.scala, "RT" = src/test/scala/RspChainVanillaTester.scala.
+ */
+#include "rsp_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* ------------------------------------------------------------------ wire formats */
+
+/* Utils:105-109 (formAXI4StreamComplexData): two 16-digit two's-complement
+ * strings concatenated, real first. */
+uint32_t orc_pack_iq(int32_t re, int32_t im) {
+  return ((uint32_t)(re & 0xFFFF) << 16) | (uint32_t)(im & 0xFFFF);
+}
+
+void orc_unpack_iq(uint32_t beat, int16_t* re, int16_t* im) {
+  *re = (int16_t)(beat >> 16);
+  *im = (int16_t)(beat & 0xFFFF);
+}
+
+/* Tester:153,163-167: threshold above bit log2N+1, bin in the middle, peak = bit 0. */
+uint32_t orc_pack_out(uint32_t thr, uint32_t bin, uint32_t peak, int log2n) {
+  return (thr << (log2n + 1)) | ((bin & ((1u << log2n) - 1u)) << 1) | (peak & 1u);
+}
+
+/* ------------------------------------------------------------------ fixed-point FFT */
+
+/* Arithmetic right shift by n with the FFT's trim type.  BUILD-DEFINED: the
+ * reference passes no trimType at Chain:78-90, so upstream's default applies
+ * (believed Convergent, unverifiable). */
+static int64_t trim_shift(int64_t x, int n, int trim) {
+  if (n <= 0) return x << (-n);
+  switch (trim) {
+    case ORC_TRIM_FLOOR:
+      return x >> n;
+    case ORC_TRIM_HALF_UP:
+      return (x + ((int64_t)1 << (n - 1))) >> n;
+    default: { /* convergent: ties to even */
+      int64_t t = x + ((int64_t)1 << (n - 1));
+      int64_t r = t >> n;
+      if ((t & (((int64_t)1 << n) - 1)) == 0) r &= ~(int64_t)1;
+      return r;
+    }
+  }
+}
+
+/* dataWidth = 16 (Chain:79): results wrap like a 16-bit register. */
+static int16_t wrap16(int64_t x) { return (int16_t)(uint16_t)(x & 0xFFFF); }
+
+/* twiddleWidth = 16 (Chain:80), BP = 14: W_N^k = exp(-2 pi i k / N), rounded to
+ * nearest (BUILD-DEFINED rounding of the ROM contents). */
+void orc_twiddles_q14(int log2n, int16_t* wr, int16_t* wi) {
+  int n = 1 << log2n;
+  for (int k = 0; k < n / 2; k++) {
+    double a = -2.0 * M_PI * (double)k / (double)n;
+    wr[k] = (int16_t)lround(cos(a) * 16384.0);
+    wi[k] = (int16_t)lround(sin(a) * 16384.0);
+  }
+}
+
+static unsigned bitrev(unsigned x, int bits) {
+  unsigned r = 0;
+  for (int i = 0; i < bits; i++) {
+    r = (r << 1) | (x & 1u);
+    x >>= 1;
+  }
+  return r;
+}
+
+/*
+ * The SDF pipeline computes, stage by stage, the radix-2 decimation-in-frequency
+ * butterfly graph: stage s pairs samples half = N >> (s+1) apart (the depth of
+ * that stage's delay-feedback line), forwards a+b, and feeds (a-b) * W to the
+ * next stage.  With expandLogic = 0 and keepMSBorLSB = true (Chain:86-87) each
+ * stage's (w+1)-bit result is cut back to w bits by dropping its LSB, so every
+ * stage halves and the net gain is 1/N (Tester:77 divides the float model by
+ * fftSize).  BUILD-DEFINED: one rounding per output -- (a+b) is trimmed by 1
+ * bit, (a-b)*W by 15 bits (14 twiddle fraction bits + the dropped LSB).
+ * The bit-reversed result is reordered (useBitReverse = true, Chain:82).
+ */
+void orc_fft_fixed(const int16_t* re_in, const int16_t* im_in, int log2n, int trim,
+                   int16_t* re_out, int16_t* im_out) {
+  int n = 1 << log2n;
+  int16_t* xr = (int16_t*)malloc(sizeof(int16_t) * (size_t)n);
+  int16_t* xi = (int16_t*)malloc(sizeof(int16_t) * (size_t)n);
+  int16_t* wr = (int16_t*)malloc(sizeof(int16_t) * (size_t)(n / 2 + 1));
+  int16_t* wi = (int16_t*)malloc(sizeof(int16_t) * (size_t)(n / 2 + 1));
+  memcpy(xr, re_in, sizeof(int16_t) * (size_t)n);
+  memcpy(xi, im_in, sizeof(int16_t) * (size_t)n);
+  orc_twiddles_q14(log2n, wr, wi);
+  for (int s = 0; s < log2n; s++) {
+    int half = n >> (s + 1);
+    for (int base = 0; base < n; base += 2 * half) {
+      for (int j = 0; j < half; j++) {
+        int a = base + j, b = a + half;
+        int k = j << s; /* W_{2*half}^j == W_N^(j * 2^s) */
+        int64_t sr = (int64_t)xr[a] + xr[b], si = (int64_t)xi[a] + xi[b];
+        int64_t dr = (int64_t)xr[a] - xr[b], di = (int64_t)xi[a] - xi[b];
+        int64_t pr = dr * wr[k] - di * wi[k];
+        int64_t pi = dr * wi[k] + di * wr[k];
+        xr[a] = wrap16(trim_shift(sr, 1, trim));
+        xi[a] = wrap16(trim_shift(si, 1, trim));
+        xr[b] = wrap16(trim_shift(pr, 15, trim));
+        xi[b] = wrap16(trim_shift(pi, 15, trim));
+      }
+    }
+  }
+  for (int k = 0; k < n; k++) {
+    unsigned p = bitrev((unsigned)k, log2n);
+    re_out[k] = xr[p];
+    im_out[k] = xi[p];
+  }
+  free(xr);
+  free(xi);
+  free(wr);
+  free(wi);
+}
+
+/* ------------------------------------------------------------------ fixed-point magnitude */
+
+static int32_t jpl_fixed(int16_t re, int16_t im) {
+  /* Utils:120-127: u = max(|re|,|im|), v = min(...), max(u + v/8, 7u/8 + v/2).
+   * BUILD-DEFINED: each division is a floor shift; result saturates at the
+   * signed 16-bit maximum of MAGParams dataWidth (Chain:92). */
+  int32_t ar = re < 0 ? -(int32_t)re : re, ai = im < 0 ? -(int32_t)im : im;
+  int32_t u = ar > ai ? ar : ai, v = ar > ai ? ai : ar;
+  int32_t t1 = u + (v >> 3);
+  int32_t t2 = ((7 * u) >> 3) + (v >> 1);
+  int32_t m = t1 > t2 ? t1 : t2;
+  return m > 32767 ? 32767 : m;
+}
+
+int32_t orc_mag_fixed(int16_t re, int16_t im, const orc_cfg* c) {
+  switch (c->mag_mode) {
+    case ORC_MAG_SQR: {
+      /* Utils:205-208 "sqrMag": re^2 + im^2, kept at binPoint (BUILD-DEFINED:
+       * floor shift by binPoint, saturate to 16-bit signed). */
+      int64_t s = (int64_t)re * re + (int64_t)im * im;
+      s >>= c->bp_data;
+      return (int32_t)(s > 32767 ? 32767 : s);
+    }
+    case ORC_MAG_LOG2: {
+      /* Utils:209-212 "log2Mag" = log2(jplMag).  BUILD-DEFINED realisation:
+       * leading-one position + 2^log2LookUpWidth-entry fraction table, output
+       * Q(dataWidthLog - binPointLog).binPointLog (Chain:94-96). */
+      int32_t x = jpl_fixed(re, im);
+      if (x < 1) x = 1;
+      int e = 31 - __builtin_clz((unsigned)x);
+      int lw = c->log2_lut_width;
+      uint32_t f = e >= lw ? ((uint32_t)x >> (e - lw)) : ((uint32_t)x << (lw - e));
+      f &= (1u << lw) - 1u;
+      int32_t lut = (int32_t)llround(log2(1.0 + (double)f / (double)(1u << lw)) *
+                                     (double)(1 << c->bp_log));
+      return ((e - c->bp_data) * (1 << c->bp_log)) + lut;
+    }
+    default:
+      return jpl_fixed(re, im);
+  }
+}
+
+/* ------------------------------------------------------------------ CFAR helpers */
+
+static int cmp_i32(const void* a, const void* b) {
+  int32_t x = *(const int32_t*)a, y = *(const int32_t*)b;
+  return (x > y) - (x < y);
+}
+static int cmp_f64(const void* a, const void* b) {
+  double x = *(const double*)a, y = *(const double*)b;
+  return (x > y) - (x < y);
+}
+
+/* index of cell (k + off) under the edge policy; -1 = outside (reads as 0) */
+static int cell_index(int k, int off, int n, int edge) {
+  int j = k + off;
+  if (edge == ORC_EDGE_WRAP) return ((j % n) + n) % n;
+  return (j < 0 || j >= n) ? -1 : j;
+}
+
+/* ------------------------------------------------------------------ fixed-point CFAR */
+
+/*
+ * 1-D sliding-window CFAR over one frame.  Window geometry (Chain:105-106,
+ * Tester:120-121): [R lagging cells][G guard][CUT][G guard][R leading cells].
+ * Registers: SURVEY App. A.3 / Tester:100-132.
+ * BUILD-DEFINED (upstream cfar generator unavailable):
+ *   - per-side statistic = window sum >> divSum (CA family) or the
+ *     index-th smallest cell of the window (GOS, Tester:123-127);
+ *   - cfarMode 0 (Cell Averaging) = (lagg + lead) >> 1, 1 = max, 2 = min,
+ *     3 (CASH) = min over sides of the largest sub-window sum, >> divSum;
+ *   - linear: threshold = (statistic * scaler) >> (BP_in + BP_scaler - BP_thr);
+ *     log: threshold = statistic + scaler (both aligned to BP_thr);
+ *     saturated to the signed protoThreshold width (Chain:103);
+ *   - peak = CUT > threshold (binary points aligned), with peakGrouping also
+ *     CUT > both neighbours;
+ *   - cells outside the frame read 0 (edge 0) or wrap (edge 1).
+ * Output word: Tester:163-167.
+ */
+void orc_cfar_fixed(const int32_t* mag, const orc_cfg* c, uint32_t* out_words, int32_t* thr_out) {
+  int n = 1 << c->log2n, R = c->ref_window, G = c->guard_window;
+  int32_t* win = (int32_t*)malloc(sizeof(int32_t) * (size_t)(R > 0 ? R : 1));
+  int64_t tmax = ((int64_t)1 << (c->w_thr - 1)) - 1, tmin = -((int64_t)1 << (c->w_thr - 1));
+  for (int k = 0; k < n; k++) {
+    int64_t stat_side[2];
+    for (int side = 0; side < 2; side++) { /* 0 = lagging (k-d), 1 = leading (k+d) */
+      int64_t sum = 0;
+      for (int d = 0; d < R; d++) {
+        /* window position d = 0 is the oldest lagging cell / nearest leading cell;
+         * ordering only matters for CASH sub-windows */
+        int off = side == 0 ? -(G + R) + d : (G + 1) + d;
+        int j = cell_index(k, off, n, c->edge);
+        win[d] = j < 0 ? 0 : mag[j];
+        sum += win[d];
+      }
+      if (c->algorithm == 1) { /* GOS */
+        int idx = side == 0 ? c->index_lagg : c->index_lead;
+        qsort(win, (size_t)R, sizeof(int32_t), cmp_i32);
+        stat_side[side] = win[idx];
+      } else if (c->cfar_mode == ORC_CFAR_CASH) {
+        int sw = c->sub_window > 0 ? c->sub_window : R;
+        int64_t best = INT64_MIN;
+        for (int s0 = 0; s0 + sw <= R; s0 += sw) {
+          int64_t ss = 0;
+          for (int d = 0; d < sw; d++) ss += win[s0 + d];
+          if (ss > best) best = ss;
+        }
+        stat_side[side] = best >> c->div_sum;
+      } else {
+        stat_side[side] = sum >> c->div_sum;
+      }
+    }
+    int64_t a = stat_side[0], b = stat_side[1], stat;
+    switch (c->cfar_mode) {
+      case ORC_CFAR_CA:
+        stat = (a + b) >> 1;
+        break;
+      case ORC_CFAR_GO:
+        stat = a > b ? a : b;
+        break;
+      default: /* SO and CASH */
+        stat = a < b ? a : b;
+        break;
+    }
+    int64_t thr;
+    if (c->linear) {
+      thr = trim_shift(stat * (int64_t)c->scaler, c->bp_in + c->bp_scaler - c->bp_thr,
+                       ORC_TRIM_FLOOR);
+    } else {
+      thr = trim_shift(stat, c->bp_in - c->bp_thr, ORC_TRIM_FLOOR) +
+            trim_shift((int64_t)c->scaler, c->bp_scaler - c->bp_thr, ORC_TRIM_FLOOR);
+    }
+    if (thr > tmax) thr = tmax;
+    if (thr < tmin) thr = tmin;
+    int64_t cut = mag[k];
+    int peak = cut * ((int64_t)1 << c->bp_thr) > thr * ((int64_t)1 << c->bp_in);
+    if (c->peak_grouping) {
+      int jl = cell_index(k, -1, n, c->edge), jr = cell_index(k, 1, n, c->edge);
+      int64_t l = jl < 0 ? 0 : mag[jl], r = jr < 0 ? 0 : mag[jr];
+      peak = peak && cut > l && cut > r;
+    }
+    if (thr_out) thr_out[k] = (int32_t)thr;
+    out_words[k] = orc_pack_out((uint32_t)(int32_t)thr, (uint32_t)k, (uint32_t)peak, c->log2n);
+  }
+  free(win);
+}
+
+/* Tester:137 streams fftSize beats with TLAST on the final one; Tester:145-151
+ * collects exactly fftSize output words per frame. */
+void orc_chain_fixed(const uint32_t* in_beats, size_t n_frames, const orc_cfg* c,
+                     uint32_t* out_words) {
+  int n = 1 << c->log2n;
+  int16_t* re = (int16_t*)malloc(sizeof(int16_t) * (size_t)n * 4);
+  int16_t *im = re + n, *fr = re + 2 * n, *fi = re + 3 * n;
+  int32_t* mag = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+  for (size_t f = 0; f < n_frames; f++) {
+    for (int i = 0; i < n; i++) orc_unpack_iq(in_beats[f * (size_t)n + (size_t)i], &re[i], &im[i]);
+    orc_fft_fixed(re, im, c->log2n, c->trim, fr, fi);
+    for (int i = 0; i < n; i++) mag[i] = orc_mag_fixed(fr[i], fi[i], c);
+    orc_cfar_fixed(mag, c, out_words + f * (size_t)n, NULL);
+  }
+  free(re);
+  free(mag);
+}
+
+/* ------------------------------------------------------------------ float64 path */
+
+/* Iterative radix-2 DIT in float64, scaled by 1/N (Tester:77). */
+static void fft_f64_strided(const double* in, size_t istride, int log2n, const double* tw,
+                            double* out /* interleaved, contiguous */) {
+  int n = 1 << log2n;
+  for (int i = 0; i < n; i++) {
+    unsigned p = bitrev((unsigned)i, log2n);
+    out[2 * p] = in[2 * istride * (size_t)i];
+    out[2 * p + 1] = in[2 * istride * (size_t)i + 1];
+  }
+  for (int s = 1; s <= log2n; s++) {
+    int m = 1 << s, half = m >> 1, step = n >> s;
+    for (int base = 0; base < n; base += m) {
+      for (int j = 0; j < half; j++) {
+        double wr = tw[2 * (j * step)], wi = tw[2 * (j * step) + 1];
+        double* a = out + 2 * (base + j);
+        double* b = out + 2 * (base + j + half);
+        double tr = b[0] * wr - b[1] * wi, ti = b[0] * wi + b[1] * wr;
+        b[0] = a[0] - tr;
+        b[1] = a[1] - ti;
+        a[0] += tr;
+        a[1] += ti;
+      }
+    }
+  }
+  double sc = 1.0 / (double)n;
+  for (int i = 0; i < 2 * n; i++) out[i] *= sc;
+}
+
+static double* make_tw_f64(int log2n) {
+  int n = 1 << log2n;
+  double* tw = (double*)malloc(sizeof(double) * 2 * (size_t)(n / 2 + 1));
+  for (int k = 0; k < n / 2 + 1; k++) {
+    double a = -2.0 * M_PI * (double)k / (double)n;
+    tw[2 * k] = cos(a);
+    tw[2 * k + 1] = sin(a);
+  }
+  return tw;
+}
+
+void orc_fft_f64(const double* in, int log2n, double* out) {
+  double* tw = make_tw_f64(log2n);
+  fft_f64_strided(in, 1, log2n, tw, out);
+  free(tw);
+}
+
+double orc_mag_f64(double re, double im, int mode) {
+  double ar = fabs(re), ai = fabs(im);
+  double u = ar > ai ? ar : ai, v = ar > ai ? ai : ar;
+  double t1 = u + v / 8.0, t2 = 7.0 * u / 8.0 + v / 2.0; /* Utils:123-125 */
+  double jpl = t1 > t2 ? t1 : t2;
+  switch (mode) {
+    case ORC_MAG_SQR:
+      return re * re + im * im; /* Utils:206 */
+    case ORC_MAG_LOG2:
+      return log2(jpl > (double)FLT_MIN ? jpl : (double)FLT_MIN); /* Utils:210 */
+    default:
+      return jpl;
+  }
+}
+
+static double dmin(double a, double b) { return a < b ? a : b; }
+
+void orc_cfar_f64(const double* mag, const orc_fcfg* c, double* thr, uint8_t* peak,
+                  double* margin) {
+  int n = 1 << c->log2n, R = c->ref_window, G = c->guard_window;
+  double* win = (double*)malloc(sizeof(double) * (size_t)(R > 0 ? R : 1));
+  double div = ldexp(1.0, -c->div_sum);
+  for (int k = 0; k < n; k++) {
+    double side_stat[2];
+    for (int side = 0; side < 2; side++) {
+      double sum = 0.0;
+      for (int d = 0; d < R; d++) {
+        int off = side == 0 ? -(G + R) + d : (G + 1) + d;
+        int j = cell_index(k, off, n, c->edge);
+        win[d] = j < 0 ? 0.0 : mag[j];
+        sum += win[d];
+      }
+      if (c->algorithm == 1) {
+        int idx = side == 0 ? c->index_lagg : c->index_lead;
+        qsort(win, (size_t)R, sizeof(double), cmp_f64);
+        side_stat[side] = win[idx];
+      } else {
+        side_stat[side] = sum * div;
+      }
+    }
+    double a = side_stat[0], b = side_stat[1], stat;
+    switch (c->cfar_mode) {
+      case ORC_CFAR_CA:
+        stat = 0.5 * (a + b);
+        break;
+      case ORC_CFAR_GO:
+        stat = a > b ? a : b;
+        break;
+      default:
+        stat = a < b ? a : b;
+        break;
+    }
+    double t = c->linear ? stat * c->scaler : stat + c->scaler;
+    double cut = mag[k];
+    int p = cut > t;
+    double mg = fabs(cut - t);
+    if (c->peak_grouping) {
+      int jl = cell_index(k, -1, n, c->edge), jr = cell_index(k, 1, n, c->edge);
+      double l = jl < 0 ? 0.0 : mag[jl], r = jr < 0 ? 0.0 : mag[jr];
+      p = p && cut > l && cut > r;
+      mg = dmin(mg, dmin(fabs(cut - l), fabs(cut - r)));
+    }
+    thr[k] = t;
+    peak[k] = (uint8_t)p;
+    if (margin) margin[k] = mg;
+  }
+  free(win);
+}
+
+void orc_chain_f32in(const float* in, size_t n_frames, const orc_fcfg* c, double* thr,
+                     uint8_t* peak, double* margin, double* mag_out, int n_threads) {
+  int n = 1 << c->log2n;
+  double* tw = make_tw_f64(c->log2n);
+#ifdef _OPENMP
+#pragma omp parallel num_threads(n_threads > 0 ? n_threads : 1)
+#endif
+  {
+    double* x = (double*)malloc(sizeof(double) * 2 * (size_t)n);
+    double* y = (double*)malloc(sizeof(double) * 2 * (size_t)n);
+    double* m = (double*)malloc(sizeof(double) * (size_t)n);
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+    for (long f = 0; f < (long)n_frames; f++) {
+      const float* src = in + 2 * (size_t)f * (size_t)n;
+      for (int i = 0; i < 2 * n; i++) x[i] = (double)src[i];
+      fft_f64_strided(x, 1, c->log2n, tw, y);
+      for (int i = 0; i < n; i++) m[i] = orc_mag_f64(y[2 * i], y[2 * i + 1], c->mag_mode);
+      if (mag_out) memcpy(mag_out + (size_t)f * (size_t)n, m, sizeof(double) * (size_t)n);
+      orc_cfar_f64(m, c, thr + (size_t)f * (size_t)n, peak + (size_t)f * (size_t)n,
+                   margin ? margin + (size_t)f * (size_t)n : NULL);
+    }
+    free(x);
+    free(y);
+    free(m);
+  }
+  free(tw);
+}
+
+/* ------------------------------------------------------------------ 2-D range-Doppler */
+
+/*
+ * No reference counterpart: every chain in src/main/scala holds one
+ * 1-D FFT.  Defined by BASELINE.json configs 3/5.  Training region = the
+ * (2(ref_r+guard_r)+1) x (2(ref_d+guard_d)+1) box around the CUT minus the
+ * (2 guard_r+1) x (2 guard_d+1) guard box; statistic = training sum / training
+ * cell count (out-of-map cells count as zeros, as in the 1-D zero-edge rule);
+ * Doppler axis cyclic, range axis per c->edge.
+ */
+void orc_rd_f32in(const float* in, size_t n_ch, const orc_rdcfg* c, double* thr, uint8_t* peak,
+                  double* margin, double* mag_out, int n_threads) {
+  int nr = 1 << c->log2nr, nd = 1 << c->log2nd;
+  size_t map = (size_t)nr * (size_t)nd;
+  double* twr = make_tw_f64(c->log2nr);
+  double* twd = make_tw_f64(c->log2nd);
+  int hr = c->ref_r + c->guard_r, hd = c->ref_d + c->guard_d;
+  int er = nr + 2 * hr, ed = nd + 2 * hd; /* halo-extended map */
+  double count = (double)(2 * hr + 1) * (2 * hd + 1) - (double)(2 * c->guard_r + 1) * (2 * c->guard_d + 1);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(n_threads > 0 ? n_threads : 1)
+#endif
+  for (long ch = 0; ch < (long)n_ch; ch++) {
+    double* a = (double*)malloc(sizeof(double) * 2 * map);
+    double* b = (double*)malloc(sizeof(double) * 2 * map);
+    double* m = (double*)malloc(sizeof(double) * map);
+    double* col = (double*)malloc(sizeof(double) * 2 * (size_t)nd);
+    double* sat = (double*)calloc((size_t)(er + 1) * (size_t)(ed + 1), sizeof(double));
+    const float* src = in + 2 * map * (size_t)ch;
+    for (size_t i = 0; i < 2 * map; i++) a[i] = (double)src[i];
+    for (int d = 0; d < nd; d++) /* range FFT along r (contiguous) */
+      fft_f64_strided(a + 2 * (size_t)d * (size_t)nr, 1, c->log2nr, twr, b + 2 * (size_t)d * (size_t)nr);
+    for (int r = 0; r < nr; r++) { /* Doppler FFT along d (stride nr) */
+      fft_f64_strided(b + 2 * (size_t)r, (size_t)nr, c->log2nd, twd, col);
+      for (int d = 0; d < nd; d++)
+        m[(size_t)d * (size_t)nr + (size_t)r] = orc_mag_f64(col[2 * d], col[2 * d + 1], c->mag_mode);
+    }
+    if (mag_out) memcpy(mag_out + map * (size_t)ch, m, sizeof(double) * map);
+    /* summed-area table over the halo-extended map: sat[(d+1)*(er+1) + (r+1)] */
+    for (int d = 0; d < ed; d++) {
+      double rowsum = 0.0;
+      int sd = (((d - hd) % nd) + nd) % nd; /* Doppler always cyclic */
+      for (int r = 0; r < er; r++) {
+        int sr = cell_index(r - hr, 0, nr, c->edge);
+        rowsum += sr < 0 ? 0.0 : m[(size_t)sd * (size_t)nr + (size_t)sr];
+        sat[(size_t)(d + 1) * (size_t)(er + 1) + (size_t)(r + 1)] =
+            sat[(size_t)d * (size_t)(er + 1) + (size_t)(r + 1)] + rowsum;
+      }
+    }
+#define BOX(d0, d1, r0, r1) /* inclusive ext coords */                               \
+  (sat[(size_t)((d1) + 1) * (size_t)(er + 1) + (size_t)((r1) + 1)] -                 \
+   sat[(size_t)(d0) * (size_t)(er + 1) + (size_t)((r1) + 1)] -                       \
+   sat[(size_t)((d1) + 1) * (size_t)(er + 1) + (size_t)(r0)] +                       \
+   sat[(size_t)(d0) * (size_t)(er + 1) + (size_t)(r0)])
+    for (int d = 0; d < nd; d++) {
+      for (int r = 0; r < nr; r++) {
+        int cd = d + hd, cr = r + hr;
+        double outer = BOX(cd - hd, cd + hd, cr - hr, cr + hr);
+        double inner = BOX(cd - c->guard_d, cd + c->guard_d, cr - c->guard_r, cr + c->guard_r);
+        double t = c->scaler * (outer - inner) / count;
+        size_t o = map * (size_t)ch + (size_t)d * (size_t)nr + (size_t)r;
+        double cut = m[(size_t)d * (size_t)nr + (size_t)r];
+        thr[o] = t;
+        peak[o] = (uint8_t)(cut > t);
+        if (margin) margin[o] = fabs(cut - t);
+      }
+    }
+#undef BOX
+    free(a);
+    free(b);
+    free(m);
+    free(col);
+    free(sat);
+  }
+  free(twr);
+  free(twd);
+}

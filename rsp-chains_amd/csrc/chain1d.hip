@@ -1,0 +1,396 @@
+// Fused 1-D chain kernel: FFT -> magnitude -> CA-family CFAR, one launch.
+//
+// Replaces the stream wiring
+//   cfar.streamNode := AXI4StreamBuffer() := mag.streamNode := AXI4StreamBuffer() := fft.streamNode
+// (/root/reference/src/main/scala/FftMagCfarChain.scala:47): a frame enters as
+// 2^M beats from HBM, stays in LDS through all three blocks and leaves as 2^M
+// 32-bit words (FftMagCfarChainTester.scala:145-151,163-167).  Algorithmic HBM
+// traffic: F32 8 B in + 4 B out per cell; FIXED16 4 B in + 4 B out.
+//
+// Workgroup = frames_per_wg(M) frames x (2^M / 16) threads, 16 cells per thread.
+// CFAR sliding sums come from block-relative prefix sums held in LDS (blocks of
+// 256 cells = one 16-lane row of the scan), so a window sum is a difference of
+// two nearby prefixes plus at most one block total: exact for integers, no
+// long-range cancellation for fp32.
+#include <hip/hip_runtime.h>
+#include <float.h>
+
+#include "chain_regs.hpp"
+#include "fft_lds.hpp"
+#include "kernels.hpp"
+
+namespace rsp {
+
+// ---------------------------------------------------------------- LDS layout per frame
+template <int M>
+struct FrameLds {
+  static constexpr int N = 1 << M;
+  static constexpr int PADN = pad_slots(N);
+  static constexpr int MAG_OFF = 0;                      // 4 B x PADN
+  static constexpr int PB_OFF = 4 * PADN;                // 4 B x (PADN + 2): prefix at x = 0..N
+  static constexpr int BS_OFF = PB_OFF + 4 * (PADN + 2); // 4 B x (N/256 + 1) block totals
+  static constexpr int CFAR_BYTES = BS_OFF + 4 * (N / 256 + 1);
+  static constexpr int FFT_BYTES = 8 * PADN;             // f32x2 per slot (FIXED16 uses 4 B)
+  static constexpr int BYTES = ((CFAR_BYTES > FFT_BYTES ? CFAR_BYTES : FFT_BYTES) + 15) & ~15;
+};
+
+size_t chain1d_lds_bytes(int log2n) {
+  switch (log2n) {
+    case 8: return FrameLds<8>::BYTES * frames_per_wg(8);
+    case 9: return FrameLds<9>::BYTES * frames_per_wg(9);
+    case 10: return FrameLds<10>::BYTES * frames_per_wg(10);
+    case 11: return FrameLds<11>::BYTES * frames_per_wg(11);
+    case 12: return FrameLds<12>::BYTES * frames_per_wg(12);
+    case 13: return FrameLds<13>::BYTES * frames_per_wg(13);
+    default: return 0;
+  }
+}
+
+// ---------------------------------------------------------------- magnitude (logMagMux)
+
+// JPL approximation: RspChainTesterUtils.scala:120-127; mode select = MAG CSR 0
+// (FftMagCfarChainTester.scala:84).  Spec of the other two modes: oracle/rsp_oracle.c.
+__device__ __forceinline__ float mag_f32(f32x2 z, int mode) {
+  const float ar = fabsf(z.x), ai = fabsf(z.y);
+  const float u = fmaxf(ar, ai), v = fminf(ar, ai);
+  const float jpl = fmaxf(u + v * 0.125f, u * 0.875f + v * 0.5f);
+  if (mode == 2) return jpl;
+  if (mode == 0) return z.x * z.x + z.y * z.y;
+  return __log2f(fmaxf(jpl, FLT_MIN));
+}
+
+__device__ __forceinline__ int jpl_fx(int re, int im) {
+  const int ar = re < 0 ? -re : re, ai = im < 0 ? -im : im;
+  const int u = max(ar, ai), v = min(ar, ai);
+  const int m = max(u + (v >> 3), ((7 * u) >> 3) + (v >> 1));
+  return min(m, 32767);
+}
+
+__device__ __forceinline__ int mag_fx(int re, int im, const ChainRegs& rg,
+                                      const int16_t* __restrict__ log_lut) {
+  if (rg.mag_mode == 2) return jpl_fx(re, im);
+  if (rg.mag_mode == 0) {
+    const long long s = ((long long)re * re + (long long)im * im) >> rg.bp_data;
+    return (int)(s > 32767 ? 32767 : s);
+  }
+  int x = jpl_fx(re, im);
+  x = x < 1 ? 1 : x;
+  const int e = 31 - __clz(x);
+  const int lw = rg.lut_w;
+  unsigned f = e >= lw ? ((unsigned)x >> (e - lw)) : ((unsigned)x << (lw - e));
+  f &= (1u << lw) - 1u;
+  return (e - rg.bp_data) * (1 << rg.bp_log) + (int)log_lut[f];
+}
+
+// ---------------------------------------------------------------- CFAR arithmetic
+
+template <typename V>
+struct CfarMath;
+
+template <>
+struct CfarMath<float> {
+  static __device__ __forceinline__ float side(float sum, const ChainRegs& rg) { return sum * rg.div_f; }
+  static __device__ __forceinline__ float half_sum(float a, float b) { return 0.5f * (a + b); }
+  static __device__ __forceinline__ uint32_t finish(float stat, float cut, bool group_ok, int k,
+                                                    int log2n, const ChainRegs& rg) {
+    (void)k; (void)log2n;
+    const float thr = rg.linear ? stat * rg.scaler_f : stat + rg.scaler_f;
+    const uint32_t peak = (cut > thr) && group_ok;
+    return (__float_as_uint(thr) & ~1u) | peak;
+  }
+};
+
+template <>
+struct CfarMath<int> {
+  static __device__ __forceinline__ int side(int sum, const ChainRegs& rg) { return sum >> rg.div_sum; }
+  static __device__ __forceinline__ int half_sum(int a, int b) { return (a + b) >> 1; }
+  static __device__ __forceinline__ long long shr(long long x, int n) { return n >= 0 ? (x >> n) : (x << -n); }
+  static __device__ __forceinline__ uint32_t finish(int stat, int cut, bool group_ok, int k,
+                                                    int log2n, const ChainRegs& rg) {
+    long long thr;
+    if (rg.linear) {
+      thr = shr((long long)stat * (long long)rg.scaler_raw, rg.bp_in + rg.bp_scaler - rg.bp_thr);
+    } else {
+      thr = shr((long long)stat, rg.bp_in - rg.bp_thr) +
+            shr((long long)rg.scaler_raw, rg.bp_scaler - rg.bp_thr);
+    }
+    const long long tmax = (1ll << (rg.w_thr - 1)) - 1, tmin = -(1ll << (rg.w_thr - 1));
+    thr = thr > tmax ? tmax : (thr < tmin ? tmin : thr);
+    const uint32_t peak =
+        ((long long)cut * (1ll << rg.bp_thr) > thr * (1ll << rg.bp_in)) && group_ok;
+    return ((uint32_t)(int)thr << (log2n + 1)) | ((uint32_t)k << 1) | peak;
+  }
+};
+
+// Sum of cells [u, v), 0 <= u <= v <= N, v - u <= 256, from block-relative prefixes.
+template <typename V>
+__device__ __forceinline__ V span_sum(const V* __restrict__ pb, const V* __restrict__ bs, int u, int v) {
+  V s = pb[pad(v)] - pb[pad(u)];
+  if ((v >> 8) != (u >> 8)) s += bs[u >> 8];
+  return s;
+}
+
+// Sum of the R cells starting at cell a (may lie outside [0, N)).
+template <typename V, int N>
+__device__ __forceinline__ V window_sum(const V* pb, const V* bs, int a, int R, int edge) {
+  if (edge == 0) {
+    const int u = min(max(a, 0), N), v = min(max(a + R, 0), N);
+    return span_sum<V>(pb, bs, u, v);
+  }
+  const int a0 = (a + N) & (N - 1);
+  if (a0 + R <= N) return span_sum<V>(pb, bs, a0, a0 + R);
+  return span_sum<V>(pb, bs, a0, N) + span_sum<V>(pb, bs, 0, a0 + R - N);
+}
+
+template <typename V, int N>
+__device__ __forceinline__ V cell_or_zero(const V* mag, int j, int edge) {
+  if (edge == 0) return (j < 0 || j >= N) ? V(0) : mag[pad(j)];
+  return mag[pad((j + N) & (N - 1))];
+}
+
+// ---------------------------------------------------------------- the kernel
+
+template <int M, bool FIXED>
+__global__ void __launch_bounds__(wg_size(M))
+chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t n_frames,
+               ChainRegs rg, const void* __restrict__ tw, const int16_t* __restrict__ log_lut) {
+  constexpr int N = 1 << M, T = threads_per_frame(M), FPW = frames_per_wg(M), NP = plan_np(M);
+  using L = FrameLds<M>;
+  using V = typename std::conditional<FIXED, int, float>::type;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int fl = tid / T, tau = tid % T;
+  const uint32_t frame = blockIdx.x * FPW + fl;
+  const bool live = frame < n_frames;  // dead frames still walk every barrier
+  unsigned char* fbase = smem + fl * L::BYTES;
+
+  V mg[16];  // magnitudes of this thread's 16 bins, bin = (q << (M-WL)) | bitrev(c)
+  constexpr int WL = plan_w(M, NP - 1);
+
+  if constexpr (!FIXED) {
+    f32x2* buf = reinterpret_cast<f32x2*>(fbase);
+    const f32x2* src = reinterpret_cast<const f32x2*>(in) + (size_t)frame * N;
+    const f32x2* twf = reinterpret_cast<const f32x2*>(tw);
+    f32x2 x[16];
+    {
+      constexpr int W = plan_w(M, 0), LO = plan_lo(M, 0);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        f32x2 z = {0.f, 0.f};
+        if (live) z = src[elem_index<M, LO, W>(tau, e)];
+        x[e] = z;
+      }
+    }
+    pass_f32<M, 0>(x, tau, twf);
+    // passes 1..NP-1 through LDS
+    auto exchange = [&](auto pc) {
+      constexpr int P = decltype(pc)::value;
+      constexpr int W0 = plan_w(M, P - 1), LO0 = plan_lo(M, P - 1);
+      constexpr int W1 = plan_w(M, P), LO1 = plan_lo(M, P);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) buf[pad(elem_index<M, LO0, W0>(tau, e))] = x[e];
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 16; ++e) x[e] = buf[pad(elem_index<M, LO1, W1>(tau, e))];
+      pass_f32<M, P>(x, tau, twf);
+    };
+    exchange(std::integral_constant<int, 1>{});
+    if constexpr (NP > 2) exchange(std::integral_constant<int, 2>{});
+    if constexpr (NP > 3) exchange(std::integral_constant<int, 3>{});
+    const float scale = 1.0f / (float)N;  // net 1/N: FftMagCfarChainTester.scala:77
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mg[e] = mag_f32(x[e] * scale, rg.mag_mode);
+  } else {
+    uint32_t* buf = reinterpret_cast<uint32_t*>(fbase);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(in) + (size_t)frame * N;
+    const uint32_t* twq = reinterpret_cast<const uint32_t*>(tw);
+    int xr[16], xi[16];
+    {
+      constexpr int W = plan_w(M, 0), LO = plan_lo(M, 0);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        // beat = {re[31:16], im[15:0]}: RspChainTesterUtils.scala:105-109
+        uint32_t b = 0;
+        if (live) b = src[elem_index<M, LO, W>(tau, e)];
+        xr[e] = (int)(short)(b >> 16);
+        xi[e] = (int)(short)(b & 0xffffu);
+      }
+    }
+    pass_fx<M, 0>(xr, xi, tau, twq, rg);
+    auto exchange = [&](auto pc) {
+      constexpr int P = decltype(pc)::value;
+      constexpr int W0 = plan_w(M, P - 1), LO0 = plan_lo(M, P - 1);
+      constexpr int W1 = plan_w(M, P), LO1 = plan_lo(M, P);
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        buf[pad(elem_index<M, LO0, W0>(tau, e))] = ((uint32_t)xr[e] << 16) | ((uint32_t)xi[e] & 0xffffu);
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const uint32_t b = buf[pad(elem_index<M, LO1, W1>(tau, e))];
+        xr[e] = (int)(short)(b >> 16);
+        xi[e] = (int)(short)(b & 0xffffu);
+      }
+      pass_fx<M, P>(xr, xi, tau, twq, rg);
+    };
+    exchange(std::integral_constant<int, 1>{});
+    if constexpr (NP > 2) exchange(std::integral_constant<int, 2>{});
+    if constexpr (NP > 3) exchange(std::integral_constant<int, 3>{});
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mg[e] = mag_fx(xr[e], xi[e], rg, log_lut);
+  }
+
+  // ---- magnitudes to LDS in natural bin order (padded) ----
+  V* mag = reinterpret_cast<V*>(fbase + L::MAG_OFF);
+  V* pb = reinterpret_cast<V*>(fbase + L::PB_OFF);
+  V* bs = reinterpret_cast<V*>(fbase + L::BS_OFF);
+  __syncthreads();  // every thread is done reading the FFT image this overlays
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int g = e >> WL, p = e & ((1 << WL) - 1);
+    const int c = g * T + tau;
+    const int k = (bitrev_c(p, WL) << (M - WL)) | (int)(__brev((unsigned)c) >> (32 - (M - WL)));
+    mag[pad(k)] = mg[e];
+  }
+  __syncthreads();
+
+  // ---- block-relative exclusive prefix sums: thread owns cells 16 tau .. 16 tau + 15 ----
+  {
+    V loc[16];
+    V acc = V(0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      loc[e] = acc;
+      acc += mag[17 * tau + e];
+    }
+    V inc = acc;  // inclusive scan of chunk totals over the 16-lane row (= 256 cells)
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+      const V t = __shfl_up(inc, d, 16);
+      if ((tau & 15) >= d) inc += t;
+    }
+    V exc = __shfl_up(inc, 1, 16);
+    if ((tau & 15) == 0) exc = V(0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) pb[17 * tau + e] = exc + loc[e];
+    if ((tau & 15) == 15) bs[tau >> 4] = inc;
+    if (tau == 0) pb[pad(N)] = V(0);
+  }
+  __syncthreads();
+
+  // ---- CFAR: cell k = tau + T j; window geometry FftMagCfarChain.scala:105-106 ----
+  if (!live) return;
+  uint32_t* dst = out + (size_t)frame * N;
+  const int R = rg.R, G = rg.G;
+#pragma unroll 4
+  for (int j = 0; j < 16; ++j) {
+    const int k = tau + T * j;
+    const V lagg = CfarMath<V>::side(window_sum<V, N>(pb, bs, k - G - R, R, rg.edge), rg);
+    const V lead = CfarMath<V>::side(window_sum<V, N>(pb, bs, k + G + 1, R, rg.edge), rg);
+    V stat;
+    if (rg.cfar_mode == 0) stat = CfarMath<V>::half_sum(lagg, lead);
+    else if (rg.cfar_mode == 1) stat = lagg > lead ? lagg : lead;
+    else stat = lagg < lead ? lagg : lead;
+    const V cut = mag[pad(k)];
+    bool group_ok = true;
+    if (rg.peak_grouping) {
+      group_ok = cut > cell_or_zero<V, N>(mag, k - 1, rg.edge) &&
+                 cut > cell_or_zero<V, N>(mag, k + 1, rg.edge);
+    }
+    dst[k] = CfarMath<V>::finish(stat, cut, group_ok, k, M, rg);
+  }
+}
+
+// ---------------------------------------------------------------- launcher
+
+template <int M>
+static hipError_t launch_m(const Chain1dLaunch& a) {
+  const uint32_t fpw = frames_per_wg(M);
+  const uint32_t grid = (a.n_frames + fpw - 1) / fpw;
+  const size_t lds = FrameLds<M>::BYTES * fpw;
+  if (a.fixed) {
+    auto k = chain1d_kernel<M, true>;
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(wg_size(M)), lds, a.stream, a.in, a.out, a.n_frames,
+                       a.regs, a.twiddles, a.log_lut);
+  } else {
+    auto k = chain1d_kernel<M, false>;
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(wg_size(M)), lds, a.stream, a.in, a.out, a.n_frames,
+                       a.regs, a.twiddles, a.log_lut);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_chain1d(const Chain1dLaunch& a) {
+  if (a.n_frames == 0) return hipSuccess;
+  switch (a.log2n) {
+    case 8: return launch_m<8>(a);
+    case 9: return launch_m<9>(a);
+    case 10: return launch_m<10>(a);
+    case 11: return launch_m<11>(a);
+    case 12: return launch_m<12>(a);
+    case 13: return launch_m<13>(a);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// ---------------------------------------------------------------- detection compaction
+
+// Dense words -> compact list of the peak cells (word bit 0, Tester:165).
+__global__ void __launch_bounds__(256)
+compact_kernel(const uint32_t* __restrict__ words, uint64_t n_cells, uint32_t log2_row,
+               uint32_t log2_rows_per_frame, rsp_detection* __restrict__ list, uint32_t cap,
+               uint32_t* __restrict__ count) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  // uniform trip count so that every lane reaches the ballot
+  const uint64_t iters = (n_cells + stride - 1) / stride;
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (uint64_t it = 0; it < iters; ++it, i += stride) {
+    const bool inb = i < n_cells;
+    const uint32_t w = inb ? words[i] : 0u;
+    const bool hit = inb && (w & 1u);
+    const unsigned long long m = __ballot(hit);
+    if (m == 0ull) continue;
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = __shfl(base, 0);
+    if (hit) {
+      const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      if (slot < cap) {
+        rsp_detection d;
+        d.bin = (uint32_t)(i & ((1ull << log2_row) - 1ull));
+        const uint64_t row = i >> log2_row;
+        d.doppler = (uint32_t)(row & ((1ull << log2_rows_per_frame) - 1ull));
+        d.frame = (uint32_t)(row >> log2_rows_per_frame);
+        d.word = w;
+        list[slot] = d;
+      }
+    }
+  }
+}
+
+hipError_t launch_compact(const uint32_t* words, uint64_t n_cells, uint32_t log2_row,
+                          uint32_t log2_rows_per_frame, rsp_detection* list, uint32_t cap,
+                          uint32_t* count, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(count, 0, sizeof(uint32_t), stream);
+  if (e != hipSuccess) return e;
+  if (n_cells == 0) return hipSuccess;
+  uint64_t blocks = (n_cells + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(compact_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, words, n_cells,
+                     log2_row, log2_rows_per_frame, list, cap, count);
+  return hipGetLastError();
+}
+
+}  // namespace rsp

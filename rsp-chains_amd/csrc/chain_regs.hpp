@@ -1,0 +1,28 @@
+// Kernel-visible snapshot of the chain's register file + elaboration constants.
+// Host fills it from rsp_chain_params and the CSR writes (include/rspchain.h);
+// passed to kernels by value (lives in SGPRs / kernarg).
+#pragma once
+#include <stdint.h>
+
+namespace rsp {
+
+struct ChainRegs {
+  // FFT
+  int32_t trim_bias1, trim_bias15;  // 0 (floor) or 2^(n-1) (half-up, convergent)
+  int32_t trim_conv;                // 1 = convergent tie fix-up
+  // magnitude (MAG CSR 0 + MAGParams)
+  int32_t mag_mode, bp_data, bp_log, lut_w;
+  // CFAR (CSR 0x04..0x2C + CFARParams protos)
+  int32_t bp_in, bp_thr, w_thr, bp_scaler;
+  uint32_t scaler_raw;
+  float scaler_f;   // F32 path: scaler_raw / 2^bp_scaler
+  float div_f;      // F32 path: 2^-divSum
+  int32_t linear, div_sum, peak_grouping, algorithm, cfar_mode;
+  int32_t R, G, idx_lagg, idx_lead, sub_window, edge;
+};
+
+constexpr int kMinLog2N = 8;   // LDS scan rows are 16 lanes x 16 cells = 256 cells
+constexpr int kMaxLog2N = 13;  // 8192 points: 68 KiB LDS per frame
+constexpr int kMaxRef = 256;   // one block-boundary crossing per window at most
+
+}  // namespace rsp

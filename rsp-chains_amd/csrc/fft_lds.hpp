@@ -1,0 +1,200 @@
+// In-LDS FFT building blocks for gfx950 (wave64, 160 KiB LDS/CU).
+//
+// Replaces the reference's SDF-FFT block (AXI4FFTBlock, constructed at
+// /root/reference/src/main/scala/FftMagCfarChain.scala:33 from
+// FFTParams.fixed(...) :78-90; generator sources are an empty submodule).
+//
+// Formulation: an N = 2^M point decimation-in-frequency FFT computed in place
+// over the sample index i (M bits).  The index is cut into 2..4 bit-fields of
+// width <= 4, most significant first; one *pass* does the radix-2^w butterflies
+// of one field entirely in registers (16 samples per thread), passes exchange
+// through LDS.  The result lands bit-reversed (sample i holds bin bitrev_M(i))
+// and is consumed in that order by the magnitude stage, i.e. the reorder the
+// reference gets from useBitReverse = true costs nothing here.
+//
+//  * F32: a pass is a 2^w-point DFT with constant twiddles, then one multiply
+//    per sample by W_{2^(lo+w)}^(low*q) built from <= 4 table reads.
+//  * FIXED16: the same butterfly graph evaluated radix-2 stage by radix-2 stage
+//    with a Q2.14 twiddle per butterfly and a 1-bit trim per stage -- exactly the
+//    dataflow of the SDF pipeline, so results are bit-identical to the spec
+//    (oracle/rsp_oracle.c orc_fft_fixed) whatever the pass split.
+//
+// LDS image: sample i lives at slot i + (i >> 4) (one pad slot per 16), which
+// keeps the three access shapes used here (unit stride, 16-sample runs at a
+// 256-sample pitch, 16 consecutive samples per lane) at <= 2-way bank conflicts.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "chain_regs.hpp"
+
+namespace rsp {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__host__ __device__ constexpr int plan_np(int M) { return M <= 8 ? 2 : (M <= 12 ? 3 : 4); }
+// field widths per pass, most significant field first
+__host__ __device__ constexpr int plan_w(int M, int p) {
+  switch (M) {
+    case 8: return p < 2 ? 4 : 0;
+    case 9: return p < 3 ? 3 : 0;
+    case 10: return p == 0 ? 4 : (p < 3 ? 3 : 0);
+    case 11: return p < 2 ? 4 : (p == 2 ? 3 : 0);
+    case 12: return p < 3 ? 4 : 0;
+    case 13: return p == 0 ? 4 : (p < 4 ? 3 : 0);
+    default: return 0;
+  }
+}
+__host__ __device__ constexpr int plan_lo(int M, int p) {
+  int lo = M;
+  for (int j = 0; j <= p; ++j) lo -= plan_w(M, j);
+  return lo;
+}
+__host__ __device__ constexpr int threads_per_frame(int M) { return (1 << M) / 16; }
+__host__ __device__ constexpr int frames_per_wg(int M) {
+  return threads_per_frame(M) >= 256 ? 1 : 256 / threads_per_frame(M);
+}
+__host__ __device__ constexpr int wg_size(int M) { return threads_per_frame(M) * frames_per_wg(M); }
+__host__ __device__ constexpr int pad_slots(int n) { return n + (n >> 4); }
+
+__device__ __forceinline__ int pad(int i) { return i + (i >> 4); }
+
+// sample index of register e (0..15) of thread tau in the pass that owns field [LO, LO+W)
+template <int M, int LO, int W>
+__device__ __forceinline__ int elem_index(int tau, int e) {
+  constexpr int T = threads_per_frame(M);
+  const int g = e >> W, r = e & ((1 << W) - 1);
+  const int c = g * T + tau;
+  const int low = c & ((1 << LO) - 1), high = c >> LO;
+  return (high << (LO + W)) | (r << LO) | low;
+}
+
+__host__ __device__ constexpr int bitrev_c(int x, int bits) {
+  int r = 0;
+  for (int i = 0; i < bits; ++i) r |= ((x >> i) & 1) << (bits - 1 - i);
+  return r;
+}
+
+// ---------------------------------------------------------------- F32 pieces
+
+__device__ __forceinline__ f32x2 cmul(f32x2 a, f32x2 w) {
+  f32x2 r;
+  r.x = a.x * w.x - a.y * w.y;
+  r.y = a.x * w.y + a.y * w.x;
+  return r;
+}
+
+// d * exp(-2 pi i k16 / 16), k16 a compile-time constant after unrolling
+__device__ __forceinline__ f32x2 mul_w16(f32x2 d, int k16) {
+  constexpr float C1 = 0.92387953251128675613f, S1 = 0.38268343236508977173f;
+  constexpr float H = 0.70710678118654752440f;
+  f32x2 r;
+  switch (k16) {
+    case 0: return d;
+    case 4: r.x = d.y; r.y = -d.x; return r;
+    case 2: r.x = (d.x + d.y) * H; r.y = (d.y - d.x) * H; return r;
+    case 6: r.x = (d.y - d.x) * H; r.y = -(d.x + d.y) * H; return r;
+    case 1: r.x = d.x * C1 + d.y * S1; r.y = d.y * C1 - d.x * S1; return r;
+    case 3: r.x = d.x * S1 + d.y * C1; r.y = d.y * S1 - d.x * C1; return r;
+    case 5: r.x = d.y * C1 - d.x * S1; r.y = -d.y * S1 - d.x * C1; return r;
+    default: r.x = d.y * S1 - d.x * C1; r.y = -d.y * C1 - d.x * S1; return r;  // 7
+  }
+}
+
+// 2^W-point DIF DFT on x[g*2^W .. ), output q at position bitrev_W(q)
+template <int W>
+__device__ __forceinline__ void dft_dif(f32x2 (&x)[16], int g) {
+#pragma unroll
+  for (int st = 0; st < W; ++st) {
+    const int bl = W - 1 - st;
+#pragma unroll
+    for (int r0 = 0; r0 < (1 << W); ++r0) {
+      if (r0 & (1 << bl)) continue;
+      const int r1 = r0 | (1 << bl);
+      const int k16 = (r0 & ((1 << bl) - 1)) << (3 - bl);
+      const f32x2 a = x[g * (1 << W) + r0], b = x[g * (1 << W) + r1];
+      x[g * (1 << W) + r0] = a + b;
+      x[g * (1 << W) + r1] = mul_w16(a - b, k16);
+    }
+  }
+}
+
+// One register pass of the F32 FFT. tw = W_N^k, k < N/2 (global, L2-resident).
+template <int M, int P>
+__device__ __forceinline__ void pass_f32(f32x2 (&x)[16], int tau, const f32x2* __restrict__ tw) {
+  constexpr int W = plan_w(M, P), LO = plan_lo(M, P), G = 16 >> W, T = threads_per_frame(M);
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    dft_dif<W>(x, g);
+    if constexpr (LO > 0) {
+      const int low = (g * T + tau) & ((1 << LO) - 1);
+      const int base = low << (M - LO - W);  // W_{2^(LO+W)}^low as an exponent of W_N
+      f32x2 w[1 << W];
+      w[1] = tw[base];
+      if constexpr (W >= 2) { w[2] = tw[2 * base]; w[3] = cmul(w[1], w[2]); }
+      if constexpr (W >= 3) {
+        w[4] = tw[4 * base];
+        w[5] = cmul(w[1], w[4]); w[6] = cmul(w[2], w[4]); w[7] = cmul(w[3], w[4]);
+      }
+      if constexpr (W >= 4) {
+        w[8] = tw[8 * base];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) w[8 + q] = cmul(w[q], w[8]);
+      }
+#pragma unroll
+      for (int p = 1; p < (1 << W); ++p) {
+        const int q = bitrev_c(p, W);
+        x[g * (1 << W) + p] = cmul(x[g * (1 << W) + p], w[q]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- FIXED16 pieces
+
+// arithmetic >> n with the FFT trim type (oracle: trim_shift)
+__device__ __forceinline__ int trim_n(int x, int n, int bias, int conv) {
+  const int t = x + bias;
+  int r = t >> n;
+  const int tie = ((t & ((1 << n) - 1)) == 0) ? conv : 0;
+  return r & ~tie;
+}
+__device__ __forceinline__ int wrap16(int x) { return (int)(short)x; }
+
+// One register pass of the fixed-point FFT: radix-2 stages of field [LO, LO+W),
+// each with its own Q2.14 twiddle, (a+b) trimmed by 1 bit, (a-b)*W by 15 bits.
+// tw[k] = (wr << 16) | (wi & 0xffff) for W_N^k, k < N/2.
+template <int M, int P>
+__device__ __forceinline__ void pass_fx(int (&xr)[16], int (&xi)[16], int tau,
+                                        const uint32_t* __restrict__ tw, const ChainRegs& rg) {
+  constexpr int W = plan_w(M, P), LO = plan_lo(M, P), G = 16 >> W, T = threads_per_frame(M);
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int low = (g * T + tau) & ((1 << LO) - 1);
+#pragma unroll
+    for (int st = 0; st < W; ++st) {
+      const int bl = W - 1 - st;
+      const int s = M - 1 - (LO + bl);  // radix-2 stage number of this bit
+#pragma unroll
+      for (int r0 = 0; r0 < (1 << W); ++r0) {
+        if (r0 & (1 << bl)) continue;
+        const int r1 = r0 | (1 << bl);
+        const int jj = r0 & ((1 << bl) - 1);
+        const int e = ((jj << LO) | low) << s;
+        const uint32_t w = tw[e];
+        const int wr = (int)(short)(w >> 16), wi = (int)(short)(w & 0xffffu);
+        const int ia = g * (1 << W) + r0, ib = g * (1 << W) + r1;
+        const int sr = xr[ia] + xr[ib], si = xi[ia] + xi[ib];
+        const int dr = xr[ia] - xr[ib], di = xi[ia] - xi[ib];
+        const int pr = __mul24(dr, wr) - __mul24(di, wi);
+        const int pi = __mul24(dr, wi) + __mul24(di, wr);
+        xr[ia] = wrap16(trim_n(sr, 1, rg.trim_bias1, rg.trim_conv));
+        xi[ia] = wrap16(trim_n(si, 1, rg.trim_bias1, rg.trim_conv));
+        xr[ib] = wrap16(trim_n(pr, 15, rg.trim_bias15, rg.trim_conv));
+        xi[ib] = wrap16(trim_n(pi, 15, rg.trim_bias15, rg.trim_conv));
+      }
+    }
+  }
+}
+
+}  // namespace rsp

@@ -1,0 +1,30 @@
+// Host-visible launchers of the gfx950 kernels (chain1d.hip, rd2d.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rspchain.h"
+#include "chain_regs.hpp"
+
+namespace rsp {
+
+struct Chain1dLaunch {
+  const void* in;       // device: n_frames x 2^log2n beats (4 B FIXED16 / 8 B F32)
+  uint32_t* out;        // device: n_frames x 2^log2n words
+  uint32_t n_frames;
+  int log2n;
+  bool fixed;
+  ChainRegs regs;
+  const void* twiddles;    // device: W_N^k, k < N/2 (f32x2, or packed Q2.14 pairs)
+  const int16_t* log_lut;  // device: log2 fraction table (FIXED16, mag mode 1)
+  hipStream_t stream;
+};
+
+hipError_t launch_chain1d(const Chain1dLaunch& a);
+size_t chain1d_lds_bytes(int log2n);
+
+hipError_t launch_compact(const uint32_t* words, uint64_t n_cells, uint32_t log2_row,
+                          uint32_t log2_rows_per_frame, rsp_detection* list, uint32_t cap,
+                          uint32_t* count, hipStream_t stream);
+
+}  // namespace rsp

@@ -1,0 +1,622 @@
+// C-ABI implementation (include/rspchain.h): parameter validation, the AXI4-style
+// register file, device resources and kernel dispatch.  No CPU compute path:
+// every data-plane call ends in a gfx950 kernel launch or fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <vector>
+
+#include "../../include/rspchain.h"
+#include "chain_regs.hpp"
+#include "kernels.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess)                                                               \
+      return fail(RSP_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));       \
+  } while (0)
+
+bool is_pow2(int64_t x) { return x > 0 && (x & (x - 1)) == 0; }
+int ilog2(int64_t x) {
+  int l = 0;
+  while ((int64_t(1) << (l + 1)) <= x) ++l;
+  return l;
+}
+
+// CFAR register offsets in beats: FftMagCfarChainTester.scala:100-132
+enum CfarReg {
+  kFftSize = 0, kScaler = 1, kLogOrLinear = 2, kDivSum = 3, kPeakGrouping = 4, kAlgorithm = 5,
+  kMode = 6, kRefWindow = 7, kGuardWindow = 8, kIndexLagg = 9, kIndexLead = 10, kSubWindow = 11,
+  kNumCfarRegs = 12
+};
+
+struct TwiddleRom {
+  void* d = nullptr;
+};
+
+}  // namespace
+
+struct rsp_chain {
+  rsp_chain_params p;
+  // register file
+  uint32_t fft_stages;
+  uint32_t mag_mode;
+  uint32_t cfar[kNumCfarRegs];
+  // device state
+  int device;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::map<int, TwiddleRom> rom;  // keyed by log2n
+  int16_t* d_log_lut = nullptr;
+  void* d_in = nullptr;
+  size_t d_in_bytes = 0;
+  uint32_t* d_out = nullptr;
+  size_t d_out_bytes = 0;
+  rsp_detection* d_list = nullptr;
+  size_t d_list_cap = 0;
+  uint32_t* d_count = nullptr;
+};
+
+namespace {
+
+bool cfar_reg_present(const rsp_chain_params& p, int reg) {
+  const int alg = p.cfarParams.CFARAlgorithm;
+  switch (reg) {
+    case kDivSum: return alg != RSP_ALG_GOS;                               // Tester:105-108
+    case kAlgorithm: return alg == RSP_ALG_GOSCA;                          // Tester:110-118
+    case kIndexLagg:
+    case kIndexLead: return alg != RSP_ALG_CA;                             // Tester:123-127
+    case kSubWindow: return alg == RSP_ALG_CA && p.cfarParams.includeCASH; // Tester:129-132
+    default: return reg >= 0 && reg < kNumCfarRegs;
+  }
+}
+
+int validate(const rsp_chain_params* p) {
+  if (!p) return fail(RSP_ERR_INVALID, "params is NULL");
+  const rsp_fft_params& f = p->fftParams;
+  const rsp_mag_params& m = p->magParams;
+  const rsp_cfar_params& c = p->cfarParams;
+  if (p->beatBytes != 4)
+    return fail(RSP_ERR_UNSUPPORTED, "beatBytes = %d: the chain's streams are 32-bit (FftMagCfarChain.scala:52,62)", p->beatBytes);
+  if (p->dtype != RSP_DTYPE_FIXED16 && p->dtype != RSP_DTYPE_F32)
+    return fail(RSP_ERR_INVALID, "dtype %d", p->dtype);
+  if (!is_pow2(f.numPoints)) return fail(RSP_ERR_INVALID, "numPoints = %d is not a power of two", f.numPoints);
+  const int m_max = ilog2(f.numPoints);
+  if (m_max < rsp::kMinLog2N || m_max > rsp::kMaxLog2N)
+    return fail(RSP_ERR_UNSUPPORTED, "numPoints = %d: the GPU path holds %d..%d-point frames in LDS",
+                f.numPoints, 1 << rsp::kMinLog2N, 1 << rsp::kMaxLog2N);
+  if (f.dataWidth != 16 || f.twiddleWidth != 16)
+    return fail(RSP_ERR_UNSUPPORTED, "dataWidth/twiddleWidth = %d/%d: only the reference's 16/16 is implemented",
+                f.dataWidth, f.twiddleWidth);
+  if (!f.useBitReverse) return fail(RSP_ERR_UNSUPPORTED, "useBitReverse = false (bit-reversed output order) is not implemented");
+  for (int s = 0; s < m_max; ++s) {
+    if (f.expandLogic[s] != 0 || f.keepMSBorLSB[s] != 1)
+      return fail(RSP_ERR_UNSUPPORTED, "stage %d: only expandLogic = 0 / keepMSBorLSB = true (FftMagCfarChain.scala:86-87) is implemented", s);
+  }
+  if (f.trimType < RSP_TRIM_FLOOR || f.trimType > RSP_TRIM_CONVERGENT) return fail(RSP_ERR_INVALID, "trimType %d", f.trimType);
+  if (f.binPoint < 0 || f.binPoint > 15 || m.binPoint != f.binPoint)
+    return fail(RSP_ERR_INVALID, "binPoint fft/mag = %d/%d must agree and lie in 0..15", f.binPoint, m.binPoint);
+  if (m.dataWidth != 16 || m.dataWidthLog != 16) return fail(RSP_ERR_UNSUPPORTED, "MAGParams widths %d/%d", m.dataWidth, m.dataWidthLog);
+  if (m.log2LookUpWidth < 1 || m.log2LookUpWidth > 12 || m.binPointLog < 0 || m.binPointLog > 14)
+    return fail(RSP_ERR_INVALID, "log2LookUpWidth/binPointLog = %d/%d", m.log2LookUpWidth, m.binPointLog);
+  if (!m.useLast) return fail(RSP_ERR_UNSUPPORTED, "useLast = false: frames are delimited by TLAST on this path");
+  if (c.fftSize != f.numPoints) return fail(RSP_ERR_INVALID, "CFARParams.fftSize = %d != FFTParams.numPoints = %d", c.fftSize, f.numPoints);
+  if (!is_pow2(c.leadLaggWindowSize) || c.leadLaggWindowSize > rsp::kMaxRef)
+    return fail(c.leadLaggWindowSize > rsp::kMaxRef ? RSP_ERR_UNSUPPORTED : RSP_ERR_INVALID,
+                "leadLaggWindowSize = %d (power of two <= %d)", c.leadLaggWindowSize, rsp::kMaxRef);
+  if (c.guardWindowSize <= 0) return fail(RSP_ERR_INVALID, "guardWindowSize = %d", c.guardWindowSize);
+  if (c.sendCut) return fail(RSP_ERR_UNSUPPORTED, "sendCut = true widens the output beat beyond 32 bits; not implemented");
+  if (c.CFARAlgorithm < RSP_ALG_CA || c.CFARAlgorithm > RSP_ALG_GOSCA) return fail(RSP_ERR_INVALID, "CFARAlgorithm %d", c.CFARAlgorithm);
+  if (c.edgeMode != RSP_EDGE_ZERO && c.edgeMode != RSP_EDGE_WRAP) return fail(RSP_ERR_INVALID, "edgeMode %d", c.edgeMode);
+  const rsp_fixed_proto* protos[3] = {&c.protoIn, &c.protoThreshold, &c.protoScaler};
+  for (const rsp_fixed_proto* q : protos) {
+    if (q->width < 2 || q->width > 16 || q->binaryPoint < 0 || q->binaryPoint > 15)
+      return fail(RSP_ERR_INVALID, "FixedPoint(%d.W, %d.BP)", q->width, q->binaryPoint);
+  }
+  if (c.protoThreshold.width + m_max + 1 > 32)
+    return fail(RSP_ERR_INVALID, "threshold width %d + bin width %d + peak bit exceed the 32-bit output beat", c.protoThreshold.width, m_max);
+  const rsp_address_set* as[3] = {&p->fftAddress, &p->magAddress, &p->cfarAddress};
+  for (int i = 0; i < 3; ++i) {
+    if (as[i]->base & as[i]->mask) return fail(RSP_ERR_INVALID, "AddressSet(0x%x, 0x%x): base overlaps mask", as[i]->base, as[i]->mask);
+    for (int j = 0; j < i; ++j) {
+      const uint32_t m2 = as[i]->mask | as[j]->mask;
+      if ((as[i]->base & ~m2) == (as[j]->base & ~m2)) return fail(RSP_ERR_INVALID, "address sets %d and %d overlap", i, j);
+    }
+  }
+  if (p->cfarAddress.mask < 4 * kNumCfarRegs - 1) return fail(RSP_ERR_INVALID, "cfarAddress mask 0x%x too small for 12 registers", p->cfarAddress.mask);
+  if (p->dopplerPoints != 0) return fail(RSP_ERR_UNSUPPORTED, "dopplerPoints = %d: 2-D chain not available in this build", p->dopplerPoints);
+  return RSP_OK;
+}
+
+void reset_regs(rsp_chain* c) {
+  // RunTimeRspChainParams() defaults: RspChainVanillaTester.scala:35-48
+  const rsp_chain_params& p = c->p;
+  const int ref = std::min(32, p.cfarParams.leadLaggWindowSize);
+  c->fft_stages = (uint32_t)ilog2(p.fftParams.numPoints);
+  c->mag_mode = RSP_MAG_JPL;
+  std::memset(c->cfar, 0, sizeof(c->cfar));
+  c->cfar[kFftSize] = (uint32_t)p.cfarParams.fftSize;
+  c->cfar[kScaler] = (uint32_t)(3.5 * std::ldexp(1.0, p.cfarParams.protoThreshold.binaryPoint));  // Tester:101
+  c->cfar[kLogOrLinear] = 1;
+  c->cfar[kDivSum] = (uint32_t)ilog2(ref);
+  c->cfar[kPeakGrouping] = 0;
+  c->cfar[kAlgorithm] = 0;
+  c->cfar[kMode] = RSP_MODE_GO;
+  c->cfar[kRefWindow] = (uint32_t)ref;
+  c->cfar[kGuardWindow] = (uint32_t)std::min(4, p.cfarParams.guardWindowSize);
+  c->cfar[kIndexLagg] = (uint32_t)(ref / 2);
+  c->cfar[kIndexLead] = (uint32_t)(ref / 2);
+  c->cfar[kSubWindow] = 0;
+}
+
+bool uses_gos(const rsp_chain* c) {
+  const int alg = c->p.cfarParams.CFARAlgorithm;
+  return alg == RSP_ALG_GOS || (alg == RSP_ALG_GOSCA && c->cfar[kAlgorithm] == 1);
+}
+
+int check_regs(const rsp_chain* c) {
+  const rsp_chain_params& p = c->p;
+  const int m_max = ilog2(p.fftParams.numPoints);
+  const int m = (int)c->fft_stages;
+  if (m > m_max || m < 1) return fail(RSP_ERR_INVALID, "FFT stages = %d exceeds log2(numPoints) = %d", m, m_max);
+  if (!p.fftParams.runTime && m != m_max) return fail(RSP_ERR_INVALID, "runTime = false but stages register = %d != %d", m, m_max);
+  if (m < rsp::kMinLog2N) return fail(RSP_ERR_UNSUPPORTED, "fftSize = %d: the GPU path needs >= %d points", 1 << m, 1 << rsp::kMinLog2N);
+  const int n = 1 << m;
+  if ((int)c->cfar[kFftSize] != n)
+    return fail(RSP_ERR_INVALID, "CFAR fftSize register = %u but FFT stages register selects %d points", c->cfar[kFftSize], n);
+  if (c->mag_mode > 2) return fail(RSP_ERR_INVALID, "magnitude mode register = %u", c->mag_mode);
+  const int R = (int)c->cfar[kRefWindow], G = (int)c->cfar[kGuardWindow];
+  // require(...)s of RunTimeRspChainParams: RspChainVanillaTester.scala:50-61
+  if (!is_pow2(R)) return fail(RSP_ERR_INVALID, "refWindowSize = %d is not a power of two", R);
+  if (G <= 0) return fail(RSP_ERR_INVALID, "guardWindowSize = %d must be > 0", G);
+  if (R <= G) return fail(RSP_ERR_INVALID, "refWindowSize = %d must exceed guardWindowSize = %d", R, G);
+  if (R > p.cfarParams.leadLaggWindowSize) return fail(RSP_ERR_INVALID, "refWindowSize = %d > leadLaggWindowSize = %d", R, p.cfarParams.leadLaggWindowSize);
+  if (G > p.cfarParams.guardWindowSize) return fail(RSP_ERR_INVALID, "guardWindowSize = %d > elaborated maximum %d", G, p.cfarParams.guardWindowSize);
+  if (2 * (R + G) + 1 > n) return fail(RSP_ERR_INVALID, "window 2*(%d+%d)+1 does not fit a %d-point frame", R, G, n);
+  if (c->cfar[kMode] > 3) return fail(RSP_ERR_INVALID, "cfarMode register = %u", c->cfar[kMode]);
+  if (c->cfar[kMode] == RSP_MODE_CASH) {
+    if (!(p.cfarParams.CFARAlgorithm == RSP_ALG_CA && p.cfarParams.includeCASH))
+      return fail(RSP_ERR_INVALID, "cfarMode = CASH needs CACFARType with includeCASH = true");
+    return fail(RSP_ERR_UNSUPPORTED, "cfarMode = CASH is not implemented on the GPU path yet");
+  }
+  if (cfar_reg_present(p, kDivSum) && c->cfar[kDivSum] > 15) return fail(RSP_ERR_INVALID, "divSum = %u", c->cfar[kDivSum]);
+  if (cfar_reg_present(p, kIndexLagg)) {
+    if ((int)c->cfar[kIndexLagg] >= R || (int)c->cfar[kIndexLead] >= R)
+      return fail(RSP_ERR_INVALID, "indexLagg/indexLead = %u/%u must be < refWindowSize = %d", c->cfar[kIndexLagg], c->cfar[kIndexLead], R);
+  }
+  if (c->cfar[kAlgorithm] > 1) return fail(RSP_ERR_INVALID, "cfarAlgorithm register = %u", c->cfar[kAlgorithm]);
+  if (uses_gos(c)) return fail(RSP_ERR_UNSUPPORTED, "GOS (ordered-statistic) CFAR is not available in this build");
+  if (c->cfar[kScaler] > 0xFFFFu) return fail(RSP_ERR_INVALID, "thresholdScaler register = 0x%x exceeds protoScaler's 16 bits", c->cfar[kScaler]);
+  return RSP_OK;
+}
+
+rsp::ChainRegs snapshot(const rsp_chain* c) {
+  const rsp_chain_params& p = c->p;
+  rsp::ChainRegs r{};
+  const int trim = p.fftParams.trimType;
+  r.trim_bias1 = trim == RSP_TRIM_FLOOR ? 0 : 1;
+  r.trim_bias15 = trim == RSP_TRIM_FLOOR ? 0 : (1 << 14);
+  r.trim_conv = trim == RSP_TRIM_CONVERGENT ? 1 : 0;
+  r.mag_mode = (int)c->mag_mode;
+  r.bp_data = p.magParams.binPoint;
+  r.bp_log = p.magParams.binPointLog;
+  r.lut_w = p.magParams.log2LookUpWidth;
+  r.bp_in = p.cfarParams.protoIn.binaryPoint;
+  r.bp_thr = p.cfarParams.protoThreshold.binaryPoint;
+  r.w_thr = p.cfarParams.protoThreshold.width;
+  r.bp_scaler = p.cfarParams.protoScaler.binaryPoint;
+  r.scaler_raw = c->cfar[kScaler];
+  r.scaler_f = (float)std::ldexp((double)c->cfar[kScaler], -r.bp_scaler);
+  r.linear = c->cfar[kLogOrLinear] ? 1 : 0;
+  r.div_sum = cfar_reg_present(p, kDivSum) ? (int)c->cfar[kDivSum] : 0;
+  r.div_f = (float)std::ldexp(1.0, -r.div_sum);
+  r.peak_grouping = c->cfar[kPeakGrouping] ? 1 : 0;
+  r.algorithm = uses_gos(c) ? 1 : 0;
+  r.cfar_mode = (int)c->cfar[kMode];
+  r.R = (int)c->cfar[kRefWindow];
+  r.G = (int)c->cfar[kGuardWindow];
+  r.idx_lagg = (int)c->cfar[kIndexLagg];
+  r.idx_lead = (int)c->cfar[kIndexLead];
+  r.sub_window = (int)c->cfar[kSubWindow];
+  r.edge = p.cfarParams.edgeMode;
+  return r;
+}
+
+// Twiddle ROM W_N^k = exp(-2 pi i k / N), k < N/2, built once per frame size.
+int get_rom(rsp_chain* c, int log2n, const void** out) {
+  auto it = c->rom.find(log2n);
+  if (it != c->rom.end()) {
+    *out = it->second.d;
+    return RSP_OK;
+  }
+  const int n = 1 << log2n, half = n / 2;
+  TwiddleRom rom;
+  if (c->p.dtype == RSP_DTYPE_F32) {
+    std::vector<float> h(2 * (size_t)half);
+    for (int k = 0; k < half; ++k) {
+      const double a = -2.0 * M_PI * (double)k / (double)n;
+      h[2 * k] = (float)std::cos(a);
+      h[2 * k + 1] = (float)std::sin(a);
+    }
+    HIP_TRY(hipMalloc(&rom.d, h.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(rom.d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  } else {
+    // Q2.14 (twiddleWidth 16, FftMagCfarChain.scala:80), round to nearest
+    std::vector<uint32_t> h((size_t)half);
+    for (int k = 0; k < half; ++k) {
+      const double a = -2.0 * M_PI * (double)k / (double)n;
+      const int wr = (int)std::lround(std::cos(a) * 16384.0), wi = (int)std::lround(std::sin(a) * 16384.0);
+      h[k] = ((uint32_t)(wr & 0xFFFF) << 16) | (uint32_t)(wi & 0xFFFF);
+    }
+    HIP_TRY(hipMalloc(&rom.d, h.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(rom.d, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  c->rom[log2n] = rom;
+  *out = rom.d;
+  return RSP_OK;
+}
+
+int ensure(void** ptr, size_t* have, size_t want) {
+  if (*have >= want) return RSP_OK;
+  if (*ptr) HIP_TRY(hipFree(*ptr));
+  *ptr = nullptr;
+  *have = 0;
+  HIP_TRY(hipMalloc(ptr, want));
+  *have = want;
+  return RSP_OK;
+}
+
+size_t beat_bytes(const rsp_chain* c) { return c->p.dtype == RSP_DTYPE_F32 ? 8 : 4; }
+
+int launch_dense(rsp_chain* c, const void* d_in, size_t n_frames, uint32_t* d_out) {
+  int rc = check_regs(c);
+  if (rc != RSP_OK) return rc;
+  if (n_frames > 0x7fffffffull) return fail(RSP_ERR_INVALID, "n_frames = %zu too large for one call", n_frames);
+  if (n_frames && (!d_in || !d_out)) return fail(RSP_ERR_INVALID, "NULL buffer");
+  HIP_TRY(hipSetDevice(c->device));
+  rsp::Chain1dLaunch a{};
+  a.in = d_in;
+  a.out = d_out;
+  a.n_frames = (uint32_t)n_frames;
+  a.log2n = (int)c->fft_stages;
+  a.fixed = c->p.dtype == RSP_DTYPE_FIXED16;
+  a.regs = snapshot(c);
+  rc = get_rom(c, a.log2n, &a.twiddles);
+  if (rc != RSP_OK) return rc;
+  a.log_lut = c->d_log_lut;
+  a.stream = c->stream;
+  HIP_TRY(rsp::launch_chain1d(a));
+  return RSP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t rsp_abi_version(void) { return RSP_ABI_VERSION; }
+const char* rsp_last_error(void) { return g_err; }
+
+void rsp_chain_default_params(rsp_chain_params* p) {
+  if (!p) return;
+  std::memset(p, 0, sizeof(*p));
+  // FftMagCfarChainVanillaApp: FftMagCfarChain.scala:77-116
+  rsp_fft_params& f = p->fftParams;
+  f.dataWidth = 16;
+  f.twiddleWidth = 16;
+  f.numPoints = 1024;
+  f.useBitReverse = 1;
+  f.runTime = 1;
+  f.numAddPipes = 1;
+  f.numMulPipes = 1;
+  for (int s = 0; s < RSP_MAX_STAGES; ++s) {
+    f.expandLogic[s] = 0;
+    f.keepMSBorLSB[s] = 1;
+  }
+  f.minSRAMdepth = 1024;
+  f.binPoint = 12;
+  f.trimType = RSP_TRIM_CONVERGENT;
+  rsp_mag_params& m = p->magParams;
+  m.dataWidth = 16;
+  m.binPoint = 12;
+  m.dataWidthLog = 16;
+  m.binPointLog = 9;
+  m.log2LookUpWidth = 9;
+  m.useLast = 1;
+  m.numAddPipes = 1;
+  m.numMulPipes = 1;
+  rsp_cfar_params& c = p->cfarParams;
+  c.protoIn = {16, 12};
+  c.protoThreshold = {16, 12};
+  c.protoScaler = {16, 12};
+  c.leadLaggWindowSize = 64;
+  c.guardWindowSize = 4;
+  c.sendCut = 0;
+  c.fftSize = 1024;
+  c.minSubWindowSize = -1;
+  c.includeCASH = 0;
+  c.CFARAlgorithm = RSP_ALG_CA;
+  c.numMulPipes = 1;
+  c.edgeMode = RSP_EDGE_ZERO;
+  p->fftAddress = {0x30000100u, 0xFFu};
+  p->magAddress = {0x30000200u, 0xFFu};
+  p->cfarAddress = {0x30002000u, 0xFFFu};
+  p->beatBytes = 4;
+  p->dtype = RSP_DTYPE_FIXED16;
+  p->device = 0;
+}
+
+int rsp_chain_validate_params(const rsp_chain_params* p) { return validate(p); }
+
+int rsp_chain_create(const rsp_chain_params* p, rsp_chain** out) {
+  if (!out) return fail(RSP_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  int rc = validate(p);
+  if (rc != RSP_OK) return rc;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(RSP_ERR_DEVICE, "no HIP device: this library has no CPU path");
+  if (p->device < 0 || p->device >= ndev) return fail(RSP_ERR_DEVICE, "device %d of %d", p->device, ndev);
+  rsp_chain* c = new (std::nothrow) rsp_chain();
+  if (!c) return fail(RSP_ERR_NOMEM, "out of host memory");
+  c->p = *p;
+  c->device = p->device;
+  reset_regs(c);
+  auto bail = [&](int code) {
+    rsp_chain_destroy(c);
+    return code;
+  };
+  if (hipSetDevice(c->device) != hipSuccess) return bail(fail(RSP_ERR_DEVICE, "hipSetDevice(%d) failed", c->device));
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(RSP_ERR_DEVICE, "hipStreamCreate failed"));
+  c->stream = c->own_stream;
+  if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return bail(fail(RSP_ERR_DEVICE, "hipEventCreate failed"));
+  if (hipMalloc(reinterpret_cast<void**>(&c->d_count), sizeof(uint32_t)) != hipSuccess) return bail(fail(RSP_ERR_DEVICE, "hipMalloc failed"));
+  if (p->dtype == RSP_DTYPE_FIXED16) {
+    // log2 fraction table of the logMagMux (MAGParams log2LookUpWidth / binPointLog,
+    // FftMagCfarChain.scala:95-96); entry f = round(log2(1 + f / 2^lw) * 2^bpLog)
+    const int lw = p->magParams.log2LookUpWidth;
+    std::vector<int16_t> lut((size_t)1 << lw);
+    for (size_t i = 0; i < lut.size(); ++i)
+      lut[i] = (int16_t)std::llround(std::log2(1.0 + (double)i / (double)(1u << lw)) * (double)(1 << p->magParams.binPointLog));
+    if (hipMalloc(reinterpret_cast<void**>(&c->d_log_lut), lut.size() * sizeof(int16_t)) != hipSuccess ||
+        hipMemcpy(c->d_log_lut, lut.data(), lut.size() * sizeof(int16_t), hipMemcpyHostToDevice) != hipSuccess)
+      return bail(fail(RSP_ERR_DEVICE, "log2 table upload failed"));
+  }
+  *out = c;
+  return RSP_OK;
+}
+
+void rsp_chain_destroy(rsp_chain* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+  for (auto& kv : c->rom)
+    if (kv.second.d) (void)hipFree(kv.second.d);
+  if (c->d_log_lut) (void)hipFree(c->d_log_lut);
+  if (c->d_in) (void)hipFree(c->d_in);
+  if (c->d_out) (void)hipFree(c->d_out);
+  if (c->d_list) (void)hipFree(c->d_list);
+  if (c->d_count) (void)hipFree(c->d_count);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+static int decode(const rsp_chain* c, uint32_t addr, int* block, int* reg) {
+  const rsp_address_set* as[3] = {&c->p.fftAddress, &c->p.magAddress, &c->p.cfarAddress};
+  for (int b = 0; b < 3; ++b) {
+    if ((addr & ~as[b]->mask) == as[b]->base) {
+      const uint32_t off = addr & as[b]->mask;
+      if (off % (uint32_t)c->p.beatBytes) return fail(RSP_ERR_ADDRESS, "unaligned register address 0x%08x", addr);
+      *block = b;
+      *reg = (int)(off / (uint32_t)c->p.beatBytes);
+      return RSP_OK;
+    }
+  }
+  return fail(RSP_ERR_ADDRESS, "address 0x%08x decodes to no block", addr);
+}
+
+int rsp_chain_write_reg(rsp_chain* c, uint32_t addr, uint32_t value) {
+  if (!c) return fail(RSP_ERR_INVALID, "chain is NULL");
+  int block, reg;
+  int rc = decode(c, addr, &block, &reg);
+  if (rc != RSP_OK) return rc;
+  if (block == 0 && reg == 0) { c->fft_stages = value; return RSP_OK; }  // Tester:82
+  if (block == 1 && reg == 0) { c->mag_mode = value; return RSP_OK; }    // Tester:84
+  if (block == 2 && cfar_reg_present(c->p, reg)) { c->cfar[reg] = value; return RSP_OK; }
+  return fail(RSP_ERR_ADDRESS, "address 0x%08x: no register at offset %d of block %d in this build", addr, reg * c->p.beatBytes, block);
+}
+
+int rsp_chain_read_reg(rsp_chain* c, uint32_t addr, uint32_t* value) {
+  if (!c || !value) return fail(RSP_ERR_INVALID, "NULL argument");
+  int block, reg;
+  int rc = decode(c, addr, &block, &reg);
+  if (rc != RSP_OK) return rc;
+  if (block == 0 && reg == 0) { *value = c->fft_stages; return RSP_OK; }
+  if (block == 1 && reg == 0) { *value = c->mag_mode; return RSP_OK; }
+  if (block == 2 && cfar_reg_present(c->p, reg)) { *value = c->cfar[reg]; return RSP_OK; }
+  return fail(RSP_ERR_ADDRESS, "address 0x%08x: no register there in this build", addr);
+}
+
+int rsp_chain_check_regs(rsp_chain* c) {
+  if (!c) return fail(RSP_ERR_INVALID, "chain is NULL");
+  return check_regs(c);
+}
+
+int rsp_chain_process_device(rsp_chain* c, const void* d_in, size_t n_frames, uint32_t* d_out) {
+  if (!c) return fail(RSP_ERR_INVALID, "chain is NULL");
+  return launch_dense(c, d_in, n_frames, d_out);
+}
+
+int rsp_chain_process(rsp_chain* c, const void* in_beats, size_t n_frames, uint32_t* out_words) {
+  if (!c) return fail(RSP_ERR_INVALID, "chain is NULL");
+  int rc = check_regs(c);
+  if (rc != RSP_OK) return rc;
+  if (n_frames == 0) return RSP_OK;
+  if (!in_beats || !out_words) return fail(RSP_ERR_INVALID, "NULL buffer");
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t cells = n_frames << c->fft_stages;
+  const size_t in_bytes = cells * beat_bytes(c), out_bytes = cells * sizeof(uint32_t);
+  rc = ensure(&c->d_in, &c->d_in_bytes, in_bytes);
+  if (rc != RSP_OK) return rc;
+  rc = ensure(reinterpret_cast<void**>(&c->d_out), &c->d_out_bytes, out_bytes);
+  if (rc != RSP_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(c->d_in, in_beats, in_bytes, hipMemcpyHostToDevice, c->stream));
+  rc = launch_dense(c, c->d_in, n_frames, c->d_out);
+  if (rc != RSP_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(out_words, c->d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RSP_OK;
+}
+
+int rsp_chain_detections_device(rsp_chain* c, const uint32_t* d_out_words, size_t n_frames,
+                                rsp_detection* d_list, uint32_t cap, uint32_t* d_count) {
+  if (!c) return fail(RSP_ERR_INVALID, "chain is NULL");
+  if (!d_count || (cap && !d_list) || (n_frames && !d_out_words)) return fail(RSP_ERR_INVALID, "NULL buffer");
+  HIP_TRY(hipSetDevice(c->device));
+  const uint64_t cells = (uint64_t)n_frames << c->fft_stages;
+  HIP_TRY(rsp::launch_compact(d_out_words, cells, c->fft_stages, 0, d_list, cap, d_count, c->stream));
+  return RSP_OK;
+}
+
+int rsp_chain_process_detections(rsp_chain* c, const void* in_beats, size_t n_frames,
+                                 rsp_detection* list, size_t cap, size_t* n_found) {
+  if (!c || !n_found) return fail(RSP_ERR_INVALID, "NULL argument");
+  *n_found = 0;
+  int rc = check_regs(c);
+  if (rc != RSP_OK) return rc;
+  if (n_frames == 0) return RSP_OK;
+  if (!in_beats || (cap && !list)) return fail(RSP_ERR_INVALID, "NULL buffer");
+  if (cap > 0xffffffffull) cap = 0xffffffffull;
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t cells = n_frames << c->fft_stages;
+  rc = ensure(&c->d_in, &c->d_in_bytes, cells * beat_bytes(c));
+  if (rc != RSP_OK) return rc;
+  rc = ensure(reinterpret_cast<void**>(&c->d_out), &c->d_out_bytes, cells * sizeof(uint32_t));
+  if (rc != RSP_OK) return rc;
+  size_t list_bytes = c->d_list_cap * sizeof(rsp_detection);
+  rc = ensure(reinterpret_cast<void**>(&c->d_list), &list_bytes, std::max<size_t>(cap, 1) * sizeof(rsp_detection));
+  if (rc != RSP_OK) return rc;
+  c->d_list_cap = list_bytes / sizeof(rsp_detection);
+  HIP_TRY(hipMemcpyAsync(c->d_in, in_beats, cells * beat_bytes(c), hipMemcpyHostToDevice, c->stream));
+  rc = launch_dense(c, c->d_in, n_frames, c->d_out);
+  if (rc != RSP_OK) return rc;
+  rc = rsp_chain_detections_device(c, c->d_out, n_frames, c->d_list, (uint32_t)cap, c->d_count);
+  if (rc != RSP_OK) return rc;
+  uint32_t found = 0;
+  HIP_TRY(hipMemcpyAsync(&found, c->d_count, sizeof(found), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const size_t stored = std::min<size_t>(found, cap);
+  if (stored) HIP_TRY(hipMemcpy(list, c->d_list, stored * sizeof(rsp_detection), hipMemcpyDeviceToHost));
+  std::sort(list, list + stored, [](const rsp_detection& a, const rsp_detection& b) {
+    if (a.frame != b.frame) return a.frame < b.frame;
+    if (a.doppler != b.doppler) return a.doppler < b.doppler;
+    return a.bin < b.bin;
+  });
+  *n_found = found;
+  return RSP_OK;
+}
+
+int rsp_chain_set_stream(rsp_chain* c, void* hip_stream) {
+  if (!c) return fail(RSP_ERR_INVALID, "chain is NULL");
+  c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+  return RSP_OK;
+}
+
+int rsp_chain_synchronize(rsp_chain* c) {
+  if (!c) return fail(RSP_ERR_INVALID, "chain is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RSP_OK;
+}
+
+int rsp_chain_timer_start(rsp_chain* c) {
+  if (!c) return fail(RSP_ERR_INVALID, "chain is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  return RSP_OK;
+}
+
+int rsp_chain_timer_stop(rsp_chain* c, float* elapsed_ms) {
+  if (!c || !elapsed_ms) return fail(RSP_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  HIP_TRY(hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));
+  return RSP_OK;
+}
+
+int rsp_device_count(int* n) {
+  if (!n) return fail(RSP_ERR_INVALID, "NULL argument");
+  *n = 0;
+  int k = 0;
+  if (hipGetDeviceCount(&k) != hipSuccess) return fail(RSP_ERR_DEVICE, "hipGetDeviceCount failed (no HIP device?)");
+  *n = k;
+  return RSP_OK;
+}
+
+int rsp_device_malloc(int device, void** ptr, size_t bytes) {
+  if (!ptr) return fail(RSP_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipMalloc(ptr, bytes));
+  return RSP_OK;
+}
+
+int rsp_device_free(int device, void* ptr) {
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipFree(ptr));
+  return RSP_OK;
+}
+
+int rsp_memcpy_h2d(int device, void* dst, const void* src, size_t bytes) {
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return RSP_OK;
+}
+
+int rsp_memcpy_d2h(int device, void* dst, const void* src, size_t bytes) {
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return RSP_OK;
+}
+
+uint32_t rsp_pack_iq(int32_t re, int32_t im) {
+  return ((uint32_t)(re & 0xFFFF) << 16) | (uint32_t)(im & 0xFFFF);
+}
+
+void rsp_unpack_word(uint32_t word, int32_t log2_fft_size, int32_t* threshold, uint32_t* bin,
+                     uint32_t* peak) {
+  if (threshold) *threshold = (int32_t)word >> (log2_fft_size + 1);  // signed Int shift: Tester:164
+  if (bin) *bin = (word >> 1) & ((1u << log2_fft_size) - 1u);
+  if (peak) *peak = word & 1u;
+}
+
+void rsp_unpack_word_f32(uint32_t word, float* threshold, uint32_t* peak) {
+  if (threshold) {
+    const uint32_t b = word & ~1u;
+    std::memcpy(threshold, &b, sizeof(b));
+  }
+  if (peak) *peak = word & 1u;
+}
+
+}  // extern "C"

@@ -1,0 +1,178 @@
+"""GPU parity: the HIP path called through the C ABI vs the CPU oracle.
+FIXED16 must be bit-exact; F32 within the tolerance written in helpers.compare_f32."""
+import numpy as np
+import pytest
+
+import rsp_chains_amd as R
+from oracle import oracle as O
+from helpers import (compare_f32, make_params, oracle_cfg, oracle_fcfg, random_beats, tone_beats)
+
+pytestmark = pytest.mark.gpu
+
+
+def run_fixed(params, rt, beats):
+    with R.FftMagCfarChainVanilla(params) as dut:
+        dut.configure(rt)
+        return dut.stream(beats)
+
+
+@pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, 8192])
+def test_fixed_bit_exact_all_sizes(gpu, n):
+    params = make_params(n)
+    rt = R.RunTimeRspChainParams(fftSize=n)
+    beats = np.concatenate([tone_beats(3, n, 10 + n), random_beats(6, n, n)])  # ragged vs frames/WG
+    got = run_fixed(params, rt, beats)
+    ref = O.chain_fixed(beats, oracle_cfg(params, rt)).reshape(got.shape)
+    assert np.array_equal(got, ref)
+
+
+def test_fixed_reference_tester_procedure(gpu):
+    """FftMagCfarChainVanillaSpec (Tester:195-249) with real assertions: tones at 1/8, 1/4,
+    1/2 and the noise's DC show up as exactly the four peaks."""
+    n = 1024
+    params = make_params(n)
+    rt = R.RunTimeRspChainParams()
+    with R.FftMagCfarChainVanilla(params) as dut:
+        dut.configure(rt)
+        out = dut.stream(tone_beats(1, n, 1234))[0]
+    thr, bins, peaks = R.unpack_output(out, n)
+    assert np.array_equal(bins, np.arange(n))
+    assert list(np.nonzero(peaks)[0]) == [0, 128, 256, 512]
+    assert np.all(thr >= 0)
+
+
+@pytest.mark.parametrize("mode", ["Cell Averaging", "Greatest Of", "Smallest Of"])
+@pytest.mark.parametrize("edge", ["zero", "wrap"])
+@pytest.mark.parametrize("ref,guard", [(16, 4), (64, 2), (2, 1)])
+def test_fixed_cfar_modes(gpu, mode, edge, ref, guard):
+    n = 1024
+    params = make_params(n, edge=edge)
+    rt = R.RunTimeRspChainParams(CFARMode=mode, refWindowSize=ref, guardWindowSize=guard,
+                                 divSum=R.log2Up(ref) if ref > 1 else 0, peakGrouping=1 if ref == 16 else 0)
+    beats = np.concatenate([tone_beats(2, n, 77), random_beats(3, n, 78)])
+    got = run_fixed(params, rt, beats)
+    ref_out = O.chain_fixed(beats, oracle_cfg(params, rt)).reshape(got.shape)
+    assert np.array_equal(got, ref_out)
+
+
+@pytest.mark.parametrize("trim", ["RoundDown", "RoundHalfUp", "Convergent"])
+@pytest.mark.parametrize("mag", [0, 1, 2])
+def test_fixed_trim_and_mag_modes(gpu, trim, mag):
+    n = 512
+    params = make_params(n, trim=trim)
+    rt = R.RunTimeRspChainParams(fftSize=n, magMode=mag, logOrLinearMode=0 if mag == 1 else 1,
+                                 thresholdScaler=1.25 if mag == 1 else 3.5)
+    beats = np.concatenate([tone_beats(2, n, 5), random_beats(2, n, 6, amp=32767)])
+    got = run_fixed(params, rt, beats)
+    ref = O.chain_fixed(beats, oracle_cfg(params, rt)).reshape(got.shape)
+    assert np.array_equal(got, ref)
+
+
+def test_fixed_extreme_inputs(gpu):
+    """Full-scale and sign-corner samples: wrap-around and saturation follow the spec."""
+    n = 256
+    params = make_params(n)
+    rt = R.RunTimeRspChainParams(fftSize=n, refWindowSize=16, divSum=4)
+    rng = np.random.default_rng(3)
+    corner = rng.choice(np.array([-32768, -32767, -1, 0, 1, 32767]), size=(4, n, 2))
+    beats = O.pack_iq(corner[..., 0], corner[..., 1])
+    beats[0, :] = O.pack_iq(np.full(n, -32768), np.full(n, -32768))
+    got = run_fixed(params, rt, beats)
+    ref = O.chain_fixed(beats, oracle_cfg(params, rt)).reshape(got.shape)
+    assert np.array_equal(got, ref)
+
+
+def test_fixed_bp0_mixed_protos(gpu):
+    """RspChainVanillaSpec's formats: data BP 0, threshold BP 3, scaler BP 6
+    (RspChainVanillaTester.scala:205-239) on an NCO-like tone (bin 32)."""
+    n = 1024
+    params = make_params(n, bp=0, leadLagg=32,
+                         proto=(R.FixedPoint(16, 0), R.FixedPoint(16, 3), R.FixedPoint(16, 6)))
+    rt = R.RunTimeRspChainParams()
+    tone = R.stimulus.calcExpectedNcoOut(n, 32)
+    beats = R.stimulus.formAXI4StreamComplexData(tone)[None, :]
+    got = run_fixed(params, rt, beats)
+    ref = O.chain_fixed(beats, oracle_cfg(params, rt)).reshape(got.shape)
+    assert np.array_equal(got, ref)
+    _, _, peaks = R.unpack_output(got[0], n)
+    assert list(np.nonzero(peaks)[0]) == [32]
+
+
+def test_runtime_fft_size(gpu):
+    """runTime = true: the stages register selects a smaller FFT than numPoints (Tester:82)."""
+    params = make_params(4096)
+    rt = R.RunTimeRspChainParams(fftSize=512)
+    beats = random_beats(5, 512, 9)
+    got = run_fixed(params, rt, beats)
+    ref = O.chain_fixed(beats, oracle_cfg(params, rt)).reshape(got.shape)
+    assert np.array_equal(got, ref)
+
+
+def test_empty_and_detections(gpu):
+    n = 1024
+    params = make_params(n)
+    rt = R.RunTimeRspChainParams()
+    with R.FftMagCfarChainVanilla(params) as dut:
+        dut.configure(rt)
+        assert dut.stream(np.zeros(0, np.uint32)).shape == (0, n)
+        beats = tone_beats(7, n, 400)
+        dense = dut.stream(beats)
+        det, found = dut.detections(beats)
+        with pytest.raises(ValueError):
+            dut.stream(np.zeros(n + 1, np.uint32))  # not a whole frame
+    fr, bn = np.nonzero(dense & 1)
+    assert found == fr.size == det.size
+    assert np.array_equal(det["frame"], fr) and np.array_equal(det["bin"], bn)
+    assert np.array_equal(det["word"], dense[fr, bn])
+
+
+@pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, 8192])
+def test_f32_all_sizes(gpu, n):
+    params = make_params(n, dtype=R.F32, leadLagg=64)
+    rt = R.RunTimeRspChainParams(fftSize=n, CFARMode="Cell Averaging")
+    x = R.stimulus.chirp_frames(5, n, seed=1234 + n)
+    with R.FftMagCfarChainVanilla(params) as dut:
+        dut.configure(rt)
+        words = dut.stream(x)
+    thr, peak, margin, mag = O.chain_f32(x, oracle_fcfg(params, rt), want_mag=True)
+    compare_f32(words, thr, peak, margin, mag)
+    # the three injected targets are detected in every frame
+    assert np.all((words & 1).sum(axis=1) >= 3)
+
+
+@pytest.mark.parametrize("mode", ["Cell Averaging", "Greatest Of", "Smallest Of"])
+@pytest.mark.parametrize("edge", ["zero", "wrap"])
+@pytest.mark.parametrize("mag", [0, 1, 2])
+def test_f32_modes(gpu, mode, edge, mag):
+    n = 2048
+    params = make_params(n, dtype=R.F32, edge=edge, leadLagg=256)
+    rt = R.RunTimeRspChainParams(fftSize=n, CFARMode=mode, magMode=mag, refWindowSize=128, divSum=7,
+                                 guardWindowSize=3, peakGrouping=1, logOrLinearMode=0 if mag == 1 else 1,
+                                 thresholdScaler=2.0 if mag == 1 else 3.5)
+    x = R.stimulus.chirp_frames(4, n, seed=99 + mag)
+    with R.FftMagCfarChainVanilla(params) as dut:
+        dut.configure(rt)
+        words = dut.stream(x)
+    thr, peak, margin, magr = O.chain_f32(x, oracle_fcfg(params, rt), want_mag=True)
+    compare_f32(words, thr, peak, margin, magr)
+
+
+def test_f32_linearity_full_batch(gpu):
+    """Size-independent property at BASELINE.json's full cfg-2 size (4096 chirps x 4096 points):
+    the chain is homogeneous of degree 1 (JPL magnitude, linear CFAR), so scaling the input by 2^-3
+    scales every threshold by exactly 2^-3 and leaves every peak flag unchanged."""
+    n, frames = 4096, 4096
+    params = make_params(n, dtype=R.F32)
+    rt = R.RunTimeRspChainParams(fftSize=n, CFARMode="Cell Averaging")
+    x = R.stimulus.chirp_frames(64, n, seed=1234)
+    x = np.tile(x, (frames // 64, 1))
+    with R.FftMagCfarChainVanilla(params) as dut:
+        dut.configure(rt)
+        a = dut.stream(x)
+        b = dut.stream(x * np.float32(0.125))
+    ta, pa = R.unpack_output_f32(a)
+    tb, pb = R.unpack_output_f32(b)
+    assert np.array_equal(pa, pb)
+    assert np.array_equal(ta * np.float32(0.125), tb)
+    # identical frames give identical rows (no cross-frame state)
+    assert np.array_equal(a[:64], a[64:128])
