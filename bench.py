@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark: range-Doppler cells/s through FFT -> logMag -> CFAR on MI355X.
+
+  python bench.py --gpus 1 --steps 50 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): 1 channel, 4096-point range FFT + JPL magnitude +
+CA-CFAR (R = 32, G = 4), 4096-chirp batch, fp32 -- 16 777 216 cells per step per GPU.
+A step = one pass of the fused chain kernel over one batch already resident in HBM,
+plus the compaction of its peak cells into a detection list.  Multi-GPU: chirps shard
+embarrassingly (weak scaling: every rank owns a full batch); the only collective is
+the RCCL all-gather of the detection lists, issued on a side stream so that it
+overlaps the next step's kernel.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (chain1d):
+algorithmic bytes (12 B/cell: 8 in + 4 out) / its mean launch duration,
+measured with HIP events on the kernel's stream, against HBM peak 8.0 TB/s.
+`cpu_baseline` = the CPU oracle (oracle/rsp_oracle.c, float64 port; the reference's
+Chisel simulation cannot run here) timed on this box's host cores, N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+N_SETS = 4             # rotate 4 x (134 MB in + 67 MB out) = 805 MB > 2 x the 256 MiB Infinity Cache
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--fft", type=int, default=4096)
+    ap.add_argument("--chirps", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-json", default=None, help="PMC-derived HBM bytes/launch (profiles/*.json)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import rsp_chains_amd as R
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; no HIP device visible")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+
+    n, frames = args.fft, args.chirps
+    cells = n * frames
+    params = R.FftMagCfarVanillaParameters(
+        fftParams=R.FFTParams.fixed(numPoints=n), magParams=R.MAGParams.fixed(),
+        cfarParams=R.CFARParams(fftSize=n), dtype=R.F32, device=local_rank)
+    rt = R.RunTimeRspChainParams(fftSize=n, CFARMode="Cell Averaging", refWindowSize=32,
+                                 guardWindowSize=4, divSum=5, thresholdScaler=3.5)
+    dut = R.FftMagCfarChainVanilla(params)
+    dut.configure(rt)
+    main_stream = torch.cuda.current_stream()
+    dut.set_stream(main_stream.cuda_stream)
+
+    # ---- synthetic chirp frames, generated on the device (3 point targets of
+    # amplitude 0.4/0.2/0.1 at random range bins + complex white noise, sigma 0.05) ----
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    t = torch.arange(n, device=dev, dtype=torch.float32)
+    ins, outs, lists, counts = [], [], [], []
+    cap = 1 << 16
+    for s in range(N_SETS):
+        x = 0.05 * torch.randn(frames, n, 2, device=dev, generator=g)
+        bins = torch.randint(0, n, (frames, 3), device=dev, generator=g).to(torch.float32)
+        for j, a in enumerate((0.4, 0.2, 0.1)):
+            ph = (2 * np.pi / n) * ((bins[:, j:j + 1] * t[None, :]) % n)
+            x[..., 0] += a * torch.cos(ph)
+            x[..., 1] += a * torch.sin(ph)
+        ins.append(x.contiguous())
+        outs.append(torch.empty(frames, n, dtype=torch.int32, device=dev))
+        lists.append(torch.empty(cap, 4, dtype=torch.int32, device=dev))
+        counts.append(torch.zeros(1, dtype=torch.int32, device=dev))
+    if world > 1:
+        comm_stream = torch.cuda.Stream(device=dev)
+        g_lists = [torch.empty(world * cap, 4, dtype=torch.int32, device=dev) for _ in range(N_SETS)]
+        g_counts = [torch.empty(world, dtype=torch.int32, device=dev) for _ in range(N_SETS)]
+        ready = [torch.cuda.Event() for _ in range(N_SETS)]     # list of set s written
+        gathered = [torch.cuda.Event() for _ in range(N_SETS)]  # list of set s gathered (reusable)
+
+    def step(i):
+        s = i % N_SETS
+        if world > 1 and i >= N_SETS:
+            main_stream.wait_event(gathered[s])  # do not overwrite a list still being gathered
+        dut.process_device(ins[s].data_ptr(), frames, outs[s].data_ptr())
+        dut.detections_device(outs[s].data_ptr(), frames, lists[s].data_ptr(), cap, counts[s].data_ptr())
+        if world > 1:
+            ready[s].record(main_stream)
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(ready[s])
+                dist.all_gather_into_tensor(g_counts[s], counts[s])
+                dist.all_gather_into_tensor(g_lists[s], lists[s])
+                gathered[s].record(comm_stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- dominant kernel alone, HIP events on its own stream (same stream as the launches) ----
+    kt = []
+    for rep in range(3):
+        torch.cuda.synchronize()
+        dut.timer_start()
+        for i in range(args.steps):
+            s = i % N_SETS
+            dut.process_device(ins[s].data_ptr(), frames, outs[s].data_ptr())
+        kt.append(dut.timer_stop() / args.steps)
+    kernel_ms = float(np.median(kt))
+
+    n_det = int(counts[(args.warmup + args.steps - 1) % N_SETS].item())
+
+    if rank == 0:
+        bytes_per_launch = 12.0 * cells
+        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tj = args.traffic_json or os.path.join(ROOT, "profiles", "traffic_r01.json")
+        if os.path.exists(tj):
+            try:
+                traffic = json.load(open(tj)).get("chain1d_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "range-Doppler cells/sec (FFT+CFAR)",
+            "value": cells * world * args.steps / elapsed,
+            "unit": "cells/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cfg2: 1-ch {n}-pt range FFT + JPL logMag + CA-CFAR (R=32,G=4), "
+                                   f"{frames}-chirp batch per GPU, fp32, dense words + detection list",
+                       "cells_per_step_per_gpu": cells, "buffer_sets": N_SETS,
+                       "detections_last_step": n_det,
+                       "sharding": "chirps/channels per rank; RCCL all-gather of detection lists only"},
+            "roofline": {"bound": "hbm", "kernel": "chain1d_kernel<12,f32>",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "frac_of_measured_copy_6290": achieved / 6290.0},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(ins[0], n, frames)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(x_dev, n, frames):
+    """The oracle as the timed CPU baseline (kind "port": the reference's Chisel/verilator
+    simulation cannot be built here).  Sample: the first `sample` chirps of the same batch."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    sample = min(frames, 2048)
+    x = x_dev[:sample].cpu().numpy().view(np.complex64).reshape(sample, n)
+    cfg = O.default_fcfg(log2n=n.bit_length() - 1, cfar_mode=O.CFAR_CA, ref_window=32, guard_window=4,
+                         div_sum=5, scaler=3.5)
+    O.chain_f32(x[:64], cfg, n_threads=cores)  # warm-up (thread pool, page faults)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        O.chain_f32(x, cfg, n_threads=cores)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt > 10.0 or reps >= 20:
+            break
+    return {"value": sample * n * reps / dt, "unit": "cells/s", "cores": cores, "kind": "port",
+            "sample": f"{sample} of {frames} chirps x {n} points, {reps} passes, float64 oracle, OpenMP x{cores}"}
+
+
+if __name__ == "__main__":
+    main()
