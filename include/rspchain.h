@@ -178,6 +178,15 @@ int rsp_chain_process(rsp_chain* c, const void* in_beats, size_t n_frames, uint3
 /* Same with buffers already resident in HBM; asynchronous on the chain's stream. */
 int rsp_chain_process_device(rsp_chain* c, const void* d_in_beats, size_t n_frames,
                              uint32_t* d_out_words);
+/* Fused form: one pass produces the dense words (d_out_words may be NULL to skip
+ * them: detection-list-only output, 8 B read per cell and no dense write) AND the
+ * compact detection list.  Each frame contributes at most RSP_FRAME_DET_CAP peaks
+ * to the list; *d_count (device uint32) still counts every peak found, so
+ * *d_count > entries stored reveals truncation (by cap or by the per-frame limit). */
+#define RSP_FRAME_DET_CAP 64
+int rsp_chain_process_detect_device(rsp_chain* c, const void* d_in_beats, size_t n_frames,
+                                    uint32_t* d_out_words, rsp_detection* d_list, uint32_t cap,
+                                    uint32_t* d_count);
 /* Compact the peak cells of a dense device result into list[0..cap) (device
  * memory); *d_count (device uint32) receives the number found (may exceed cap;
  * only cap entries are stored).  Order within the list is unspecified. */
@@ -195,6 +204,11 @@ int rsp_chain_synchronize(rsp_chain* c);
 /* hipEvent pair on the chain's stream around whatever is enqueued between the calls. */
 int rsp_chain_timer_start(rsp_chain* c);
 int rsp_chain_timer_stop(rsp_chain* c, float* elapsed_ms); /* synchronises */
+/* Per-launch timing of the dominant (chain) kernel alone: while enabled, every data-plane
+ * call brackets that kernel with a HIP event pair on the chain's stream; _read
+ * synchronises, returns the summed durations and the number of launches, and resets. */
+int rsp_chain_profile_enable(rsp_chain* c, int on);
+int rsp_chain_profile_read(rsp_chain* c, float* total_ms, uint32_t* launches);
 int rsp_device_count(int* n);
 int rsp_device_malloc(int device, void** ptr, size_t bytes);
 int rsp_device_free(int device, void* ptr);

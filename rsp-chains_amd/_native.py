@@ -71,12 +71,15 @@ SIGNATURES = {
     "rsp_chain_check_regs": (C.c_int, [C.c_void_p]),
     "rsp_chain_process": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rsp_chain_process_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rsp_chain_process_detect_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "rsp_chain_detections_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_void_p]),
     "rsp_chain_process_detections": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _P(C.c_size_t)]),
     "rsp_chain_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rsp_chain_synchronize": (C.c_int, [C.c_void_p]),
     "rsp_chain_timer_start": (C.c_int, [C.c_void_p]),
     "rsp_chain_timer_stop": (C.c_int, [C.c_void_p, _P(C.c_float)]),
+    "rsp_chain_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "rsp_chain_profile_read": (C.c_int, [C.c_void_p, _P(C.c_float), _P(C.c_uint32)]),
     "rsp_device_count": (C.c_int, [_P(C.c_int)]),
     "rsp_device_malloc": (C.c_int, [C.c_int, _P(C.c_void_p), C.c_size_t]),
     "rsp_device_free": (C.c_int, [C.c_int, C.c_void_p]),

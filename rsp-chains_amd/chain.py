@@ -344,6 +344,12 @@ class FftMagCfarChainVanilla:
     def process_device(self, d_in: int, n_frames: int, d_out: int):
         _check(self._lib.rsp_chain_process_device(self._h, C.c_void_p(d_in), n_frames, C.c_void_p(d_out)))
 
+    def process_detect_device(self, d_in: int, n_frames: int, d_out: int, d_list: int, cap: int, d_count: int):
+        """Fused dense words (d_out may be 0 = skip) + compact detection list."""
+        _check(self._lib.rsp_chain_process_detect_device(self._h, C.c_void_p(d_in), n_frames,
+                                                         C.c_void_p(d_out) if d_out else None,
+                                                         C.c_void_p(d_list), cap, C.c_void_p(d_count)))
+
     def detections_device(self, d_words: int, n_frames: int, d_list: int, cap: int, d_count: int):
         _check(self._lib.rsp_chain_detections_device(self._h, C.c_void_p(d_words), n_frames,
                                                      C.c_void_p(d_list), cap, C.c_void_p(d_count)))
@@ -353,6 +359,15 @@ class FftMagCfarChainVanilla:
 
     def synchronize(self):
         _check(self._lib.rsp_chain_synchronize(self._h))
+
+    def profile_enable(self, on: bool = True):
+        _check(self._lib.rsp_chain_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        """(summed chain-kernel ms, launches) since enable / the last read."""
+        ms, k = C.c_float(), C.c_uint32()
+        _check(self._lib.rsp_chain_profile_read(self._h, C.byref(ms), C.byref(k)))
+        return ms.value, k.value
 
     def timer_start(self):
         _check(self._lib.rsp_chain_timer_start(self._h))

@@ -22,17 +22,33 @@
 namespace rsp {
 
 // ---------------------------------------------------------------- LDS layout per frame
+// After the FFT the frame's LDS is re-used for the CFAR working set (4-byte slots):
+//   mag : cell x in [-16, N+16)   at slot pad(x + 16)    (1-cell halo for peak grouping)
+//   pb  : cell x in [-256, N+256] at slot pad(x + 256)   block-relative exclusive prefix
+//   bs  : block b in [-1, N/256]  at slot b + 1          block totals
+//   det : detection staging (count + kFrameDetCap x {bin, word})
+// The halos hold zeros (edge = zero) or wrapped copies (edge = wrap), so the
+// per-cell CFAR code needs no clamping and no edge branches.
+constexpr int kHalo = 256;  // >= refWindow + guardWindow + 1 (checked on the host)
+
 template <int M>
 struct FrameLds {
   static constexpr int N = 1 << M;
   static constexpr int PADN = pad_slots(N);
-  static constexpr int MAG_OFF = 0;                      // 4 B x PADN
-  static constexpr int PB_OFF = 4 * PADN;                // 4 B x (PADN + 2): prefix at x = 0..N
-  static constexpr int BS_OFF = PB_OFF + 4 * (PADN + 2); // 4 B x (N/256 + 1) block totals
-  static constexpr int CFAR_BYTES = BS_OFF + 4 * (N / 256 + 1);
+  static constexpr int MAG_SLOTS = pad_slots(N + 32) + 1;
+  static constexpr int PB_SLOTS = pad_slots(N + 2 * kHalo) + 2;
+  static constexpr int BS_SLOTS = N / 256 + 2;
+  static constexpr int MAG_OFF = 0;
+  static constexpr int PB_OFF = MAG_OFF + 4 * MAG_SLOTS;
+  static constexpr int BS_OFF = PB_OFF + 4 * PB_SLOTS;
+  static constexpr int DET_OFF = (BS_OFF + 4 * BS_SLOTS + 7) & ~7;
+  static constexpr int CFAR_BYTES = DET_OFF + 8 + 8 * kFrameDetCap;
   static constexpr int FFT_BYTES = 8 * PADN;             // f32x2 per slot (FIXED16 uses 4 B)
   static constexpr int BYTES = ((CFAR_BYTES > FFT_BYTES ? CFAR_BYTES : FFT_BYTES) + 15) & ~15;
 };
+
+__device__ __forceinline__ int mag_slot(int x) { return pad(x + 16); }
+__device__ __forceinline__ int pb_slot(int x) { return pad(x + kHalo); }
 
 size_t chain1d_lds_bytes(int log2n) {
   switch (log2n) {
@@ -122,39 +138,20 @@ struct CfarMath<int> {
   }
 };
 
-// Sum of cells [u, v), 0 <= u <= v <= N, v - u <= 256, from block-relative prefixes.
-template <typename V>
-__device__ __forceinline__ V span_sum(const V* __restrict__ pb, const V* __restrict__ bs, int u, int v) {
-  V s = pb[pad(v)] - pb[pad(u)];
-  if ((v >> 8) != (u >> 8)) s += bs[u >> 8];
-  return s;
-}
-
-// Sum of the R cells starting at cell a (may lie outside [0, N)).
-template <typename V, int N>
-__device__ __forceinline__ V window_sum(const V* pb, const V* bs, int a, int R, int edge) {
-  if (edge == 0) {
-    const int u = min(max(a, 0), N), v = min(max(a + R, 0), N);
-    return span_sum<V>(pb, bs, u, v);
-  }
-  const int a0 = (a + N) & (N - 1);
-  if (a0 + R <= N) return span_sum<V>(pb, bs, a0, a0 + R);
-  return span_sum<V>(pb, bs, a0, N) + span_sum<V>(pb, bs, 0, a0 + R - N);
-}
-
-template <typename V, int N>
-__device__ __forceinline__ V cell_or_zero(const V* mag, int j, int edge) {
-  if (edge == 0) return (j < 0 || j >= N) ? V(0) : mag[pad(j)];
-  return mag[pad((j + N) & (N - 1))];
-}
-
 // ---------------------------------------------------------------- the kernel
 
 template <int M, bool FIXED>
 __global__ void __launch_bounds__(wg_size(M))
 chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t n_frames,
-               ChainRegs rg, const void* __restrict__ tw, const int16_t* __restrict__ log_lut) {
+               ChainRegs rg, const void* __restrict__ tw, const int16_t* __restrict__ log_lut,
+               uint32_t* __restrict__ fcount, uint2* __restrict__ fdet,
+               uint32_t* __restrict__ zero_a, uint32_t* __restrict__ zero_b) {
   constexpr int N = 1 << M, T = threads_per_frame(M), FPW = frames_per_wg(M), NP = plan_np(M);
+  // counters of the compaction launch that follows on this stream (saves two memset nodes)
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (zero_a) *zero_a = 0u;
+    if (zero_b) *zero_b = 0u;
+  }
   using L = FrameLds<M>;
   using V = typename std::conditional<FIXED, int, float>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -241,28 +238,36 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
     for (int e = 0; e < 16; ++e) mg[e] = mag_fx(xr[e], xi[e], rg, log_lut);
   }
 
-  // ---- magnitudes to LDS in natural bin order (padded) ----
+  // ---- magnitudes to LDS in natural bin order ----
   V* mag = reinterpret_cast<V*>(fbase + L::MAG_OFF);
   V* pb = reinterpret_cast<V*>(fbase + L::PB_OFF);
-  V* bs = reinterpret_cast<V*>(fbase + L::BS_OFF);
+  V* bs = reinterpret_cast<V*>(fbase + L::BS_OFF) + 1;  // bs[-1] .. bs[N/256]
+  uint32_t* det_cnt = reinterpret_cast<uint32_t*>(fbase + L::DET_OFF);
+  uint2* det_stage = reinterpret_cast<uint2*>(fbase + L::DET_OFF + 8);
+  const bool wrap = rg.edge != 0;
   __syncthreads();  // every thread is done reading the FFT image this overlays
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int g = e >> WL, p = e & ((1 << WL) - 1);
     const int c = g * T + tau;
     const int k = (bitrev_c(p, WL) << (M - WL)) | (int)(__brev((unsigned)c) >> (32 - (M - WL)));
-    mag[pad(k)] = mg[e];
+    mag[mag_slot(k)] = mg[e];
   }
+  if (tau == 0) *det_cnt = 0u;
   __syncthreads();
 
   // ---- block-relative exclusive prefix sums: thread owns cells 16 tau .. 16 tau + 15 ----
   {
     V loc[16];
-    V acc = V(0);
+    V acc = V(0), first = V(0), last = V(0);
+    const int m0 = mag_slot(16 * tau);  // the 16-cell chunk is contiguous in LDS
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
+      const V v = mag[m0 + e];
+      if (e == 0) first = v;
+      if (e == 15) last = v;
       loc[e] = acc;
-      acc += mag[17 * tau + e];
+      acc += v;
     }
     V inc = acc;  // inclusive scan of chunk totals over the 16-lane row (= 256 cells)
 #pragma unroll
@@ -272,33 +277,82 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
     }
     V exc = __shfl_up(inc, 1, 16);
     if ((tau & 15) == 0) exc = V(0);
+    const int p0 = pb_slot(16 * tau);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) pb[17 * tau + e] = exc + loc[e];
-    if ((tau & 15) == 15) bs[tau >> 4] = inc;
-    if (tau == 0) pb[pad(N)] = V(0);
+    for (int e = 0; e < 16; ++e) pb[p0 + e] = exc + loc[e];
+    // halos: zeros, or the wrapped image of the first / last block
+    if (tau < 16) {
+      const int ph = pb_slot(16 * tau + N);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) pb[ph + e] = wrap ? exc + loc[e] : V(0);
+    }
+    if (tau >= T - 16) {
+      const int pl = pb_slot(16 * tau - N);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) pb[pl + e] = wrap ? exc + loc[e] : V(0);
+    }
+    if ((tau & 15) == 15) {
+      const int blk = tau >> 4;
+      bs[blk] = inc;
+      if (blk == N / 256 - 1) bs[-1] = wrap ? inc : V(0);
+      if (blk == 0) bs[N / 256] = wrap ? inc : V(0);
+    }
+    if (tau == 0) {
+      pb[pb_slot(N + kHalo)] = V(0);
+      mag[mag_slot(N)] = wrap ? first : V(0);
+    }
+    if (tau == T - 1) mag[mag_slot(-1)] = wrap ? last : V(0);
   }
   __syncthreads();
 
   // ---- CFAR: cell k = tau + T j; window geometry FftMagCfarChain.scala:105-106 ----
-  if (!live) return;
-  uint32_t* dst = out + (size_t)frame * N;
-  const int R = rg.R, G = rg.G;
-#pragma unroll 4
-  for (int j = 0; j < 16; ++j) {
-    const int k = tau + T * j;
-    const V lagg = CfarMath<V>::side(window_sum<V, N>(pb, bs, k - G - R, R, rg.edge), rg);
-    const V lead = CfarMath<V>::side(window_sum<V, N>(pb, bs, k + G + 1, R, rg.edge), rg);
-    V stat;
-    if (rg.cfar_mode == 0) stat = CfarMath<V>::half_sum(lagg, lead);
-    else if (rg.cfar_mode == 1) stat = lagg > lead ? lagg : lead;
-    else stat = lagg < lead ? lagg : lead;
-    const V cut = mag[pad(k)];
-    bool group_ok = true;
-    if (rg.peak_grouping) {
-      group_ok = cut > cell_or_zero<V, N>(mag, k - 1, rg.edge) &&
-                 cut > cell_or_zero<V, N>(mag, k + 1, rg.edge);
+  // lagging cells [k-G-R, k-G), leading cells [k+G+1, k+G+R+1); a window sum is
+  // pb[v] - pb[u] (+ the total of u's block when the window crosses a block edge).
+  uint32_t* dst = (live && out) ? out + (size_t)frame * N : nullptr;
+  {
+    const int R = rg.R, G = rg.G;
+    const int xu0 = tau - G - R, xv0 = tau - G, xu1 = tau + G + 1, xv1 = tau + G + R + 1;
+    constexpr int JS = T + T / 16;  // slot stride between a thread's consecutive cells
+    const int au0 = pb_slot(xu0), av0 = pb_slot(xv0), au1 = pb_slot(xu1), av1 = pb_slot(xv1);
+    const int am = mag_slot(tau);
+    // immediate neighbours (peak grouping): +-1 cell = +-1 slot, +-2 across a pad slot
+    const int dl = ((tau & 15) == 0) ? 2 : 1, dr = ((tau & 15) == 15) ? 2 : 1;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int k = tau + T * j;
+      const int bu0 = (xu0 + T * j) >> 8, bu1 = (xu1 + T * j) >> 8;
+      const bool c0 = ((xv0 + T * j) >> 8) != bu0, c1 = ((xv1 + T * j) >> 8) != bu1;
+      V s0 = pb[av0 + JS * j] - pb[au0 + JS * j];
+      V s1 = pb[av1 + JS * j] - pb[au1 + JS * j];
+      const V f0 = bs[bu0], f1 = bs[bu1];
+      s0 += c0 ? f0 : V(0);
+      s1 += c1 ? f1 : V(0);
+      const V lagg = CfarMath<V>::side(s0, rg), lead = CfarMath<V>::side(s1, rg);
+      V stat;
+      if (rg.cfar_mode == 0) stat = CfarMath<V>::half_sum(lagg, lead);
+      else if (rg.cfar_mode == 1) stat = lagg > lead ? lagg : lead;
+      else stat = lagg < lead ? lagg : lead;
+      const V cut = mag[am + JS * j];
+      bool group_ok = true;
+      if (rg.peak_grouping) group_ok = cut > mag[am + JS * j - dl] && cut > mag[am + JS * j + dr];
+      const uint32_t word = CfarMath<V>::finish(stat, cut, group_ok, k, M, rg);
+      if (dst) dst[k] = word;
+      if (fcount && (word & 1u)) {
+        const uint32_t slot = atomicAdd(det_cnt, 1u);
+        if (slot < (uint32_t)kFrameDetCap) det_stage[slot] = make_uint2((uint32_t)k, word);
+      }
     }
-    dst[k] = CfarMath<V>::finish(stat, cut, group_ok, k, M, rg);
+  }
+
+  // ---- per-frame detection slots (no global atomics): count + first kFrameDetCap peaks ----
+  if (fcount) {
+    __syncthreads();
+    if (live) {
+      const uint32_t cnt = *det_cnt;
+      if (tau == 0) fcount[frame] = cnt;
+      for (uint32_t i = tau; i < min(cnt, (uint32_t)kFrameDetCap); i += T)
+        fdet[(size_t)frame * kFrameDetCap + i] = det_stage[i];
+    }
   }
 }
 
@@ -317,7 +371,7 @@ static hipError_t launch_m(const Chain1dLaunch& a) {
       if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(wg_size(M)), lds, a.stream, a.in, a.out, a.n_frames,
-                       a.regs, a.twiddles, a.log_lut);
+                       a.regs, a.twiddles, a.log_lut, a.frame_count, a.frame_det, a.zero_a, a.zero_b);
   } else {
     auto k = chain1d_kernel<M, false>;
     if (lds > 48 * 1024) {
@@ -326,7 +380,7 @@ static hipError_t launch_m(const Chain1dLaunch& a) {
       if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(wg_size(M)), lds, a.stream, a.in, a.out, a.n_frames,
-                       a.regs, a.twiddles, a.log_lut);
+                       a.regs, a.twiddles, a.log_lut, a.frame_count, a.frame_det, a.zero_a, a.zero_b);
   }
   return hipGetLastError();
 }
@@ -346,27 +400,89 @@ hipError_t launch_chain1d(const Chain1dLaunch& a) {
 
 // ---------------------------------------------------------------- detection compaction
 
-// Dense words -> compact list of the peak cells (word bit 0, Tester:165).
+// Per-frame slots written by chain1d_kernel -> one compact list.  One thread per
+// frame, 256 frames per workgroup, ONE global atomic per workgroup (a block of
+// the list is reserved from the scanned per-frame counts).
+// counters[0] = list allocation cursor (zeroed by the chain kernel), *d_count = peaks found.
 __global__ void __launch_bounds__(256)
-compact_kernel(const uint32_t* __restrict__ words, uint64_t n_cells, uint32_t log2_row,
-               uint32_t log2_rows_per_frame, rsp_detection* __restrict__ list, uint32_t cap,
-               uint32_t* __restrict__ count) {
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  // uniform trip count so that every lane reaches the ballot
-  const uint64_t iters = (n_cells + stride - 1) / stride;
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (uint64_t it = 0; it < iters; ++it, i += stride) {
-    const bool inb = i < n_cells;
-    const uint32_t w = inb ? words[i] : 0u;
-    const bool hit = inb && (w & 1u);
-    const unsigned long long m = __ballot(hit);
-    if (m == 0ull) continue;
-    const int lane = threadIdx.x & 63;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(count, (uint32_t)__popcll(m));
-    base = __shfl(base, 0);
-    if (hit) {
-      const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+compact_frames_kernel(const uint32_t* __restrict__ fcount, const uint2* __restrict__ fdet,
+                      uint32_t n_frames, rsp_detection* __restrict__ list, uint32_t cap,
+                      uint32_t* __restrict__ counters, uint32_t* __restrict__ d_count) {
+  __shared__ uint32_t wave_tot[4];
+  __shared__ uint32_t base_sh;
+  const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t found = f < n_frames ? fcount[f] : 0u;
+  const uint32_t mine = min(found, (uint32_t)kFrameDetCap);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = mine, tot_found = found;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(inc, d);
+    if (lane >= d) inc += t;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) tot_found += __shfl_xor(tot_found, d);
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  uint32_t off = inc - mine;
+  for (int w = 0; w < wave; ++w) off += wave_tot[w];
+  if (lane == 0 && tot_found) atomicAdd(d_count, tot_found);
+  if (threadIdx.x == 0) {
+    const uint32_t tot = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    base_sh = tot ? atomicAdd(&counters[0], tot) : 0u;
+  }
+  __syncthreads();
+  const uint32_t base = base_sh + off;
+  for (uint32_t i = 0; i < mine; ++i) {
+    if (base + i >= cap) break;
+    const uint2 e = fdet[(size_t)f * kFrameDetCap + i];
+    rsp_detection d;
+    d.frame = f;
+    d.bin = e.x;
+    d.doppler = 0;
+    d.word = e.y;
+    list[base + i] = d;
+  }
+}
+
+hipError_t launch_compact_frames(const uint32_t* fcount, const uint2* fdet, uint32_t n_frames,
+                                 rsp_detection* list, uint32_t cap, uint32_t* counters,
+                                 uint32_t* d_count, hipStream_t stream) {
+  if (n_frames == 0) return hipSuccess;
+  hipLaunchKernelGGL(compact_frames_kernel, dim3((n_frames + 255) / 256), dim3(256), 0, stream,
+                     fcount, fdet, n_frames, list, cap, counters, d_count);
+  return hipGetLastError();
+}
+
+// Dense words -> compact list of the peak cells (word bit 0, Tester:165).  Each
+// workgroup owns a contiguous run of cells: pass 1 counts its peaks, one global
+// atomic reserves its block of the list, pass 2 (words now L2-resident) writes.
+__global__ void __launch_bounds__(256)
+compact_kernel(const uint32_t* __restrict__ words, uint64_t n_cells, uint64_t cells_per_wg,
+               uint32_t log2_row, uint32_t log2_rows_per_frame, rsp_detection* __restrict__ list,
+               uint32_t cap, uint32_t* __restrict__ count) {
+  __shared__ uint32_t wave_cnt[4];
+  __shared__ uint32_t base_sh;
+  const uint64_t lo = (uint64_t)blockIdx.x * cells_per_wg;
+  const uint64_t hi = min(lo + cells_per_wg, n_cells);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t mine = 0;
+  for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) mine += words[i] & 1u;
+  uint32_t tot = mine;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
+  if (lane == 0) wave_cnt[wave] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t t = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    base_sh = t ? atomicAdd(count, t) : 0u;
+    wave_cnt[0] = 0;  // becomes the in-workgroup cursor
+  }
+  __syncthreads();
+  for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const uint32_t w = words[i];
+    if (w & 1u) {
+      const uint32_t slot = base_sh + atomicAdd(&wave_cnt[0], 1u);
       if (slot < cap) {
         rsp_detection d;
         d.bin = (uint32_t)(i & ((1ull << log2_row) - 1ull));
@@ -386,10 +502,11 @@ hipError_t launch_compact(const uint32_t* words, uint64_t n_cells, uint32_t log2
   hipError_t e = hipMemsetAsync(count, 0, sizeof(uint32_t), stream);
   if (e != hipSuccess) return e;
   if (n_cells == 0) return hipSuccess;
-  uint64_t blocks = (n_cells + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  uint64_t blocks = (n_cells + 4095) / 4096;
+  if (blocks > 4096) blocks = 4096;
+  const uint64_t per = (n_cells + blocks - 1) / blocks;
   hipLaunchKernelGGL(compact_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, words, n_cells,
-                     log2_row, log2_rows_per_frame, list, cap, count);
+                     per, log2_row, log2_rows_per_frame, list, cap, count);
   return hipGetLastError();
 }
 

@@ -23,6 +23,6 @@ struct ChainRegs {
 
 constexpr int kMinLog2N = 8;   // LDS scan rows are 16 lanes x 16 cells = 256 cells
 constexpr int kMaxLog2N = 13;  // 8192 points: 68 KiB LDS per frame
-constexpr int kMaxRef = 256;   // one block-boundary crossing per window at most
+constexpr int kMaxRef = 128;   // refWindow + guardWindow <= 256 (LDS prefix halo)
 
 }  // namespace rsp

@@ -8,6 +8,8 @@
 
 namespace rsp {
 
+constexpr int kFrameDetCap = 64;  // peaks listed per frame by the fused path
+
 struct Chain1dLaunch {
   const void* in;       // device: n_frames x 2^log2n beats (4 B FIXED16 / 8 B F32)
   uint32_t* out;        // device: n_frames x 2^log2n words
@@ -17,11 +19,20 @@ struct Chain1dLaunch {
   ChainRegs regs;
   const void* twiddles;    // device: W_N^k, k < N/2 (f32x2, or packed Q2.14 pairs)
   const int16_t* log_lut;  // device: log2 fraction table (FIXED16, mag mode 1)
+  // optional fused detection output: per-frame peak count + first kFrameDetCap {bin, word}
+  uint32_t* frame_count;   // device: n_frames, or NULL
+  uint2* frame_det;        // device: n_frames x kFrameDetCap
+  uint32_t* zero_a;        // device words zeroed by block 0 (the compaction launch's counters), or NULL
+  uint32_t* zero_b;
   hipStream_t stream;
 };
 
 hipError_t launch_chain1d(const Chain1dLaunch& a);
 size_t chain1d_lds_bytes(int log2n);
+
+hipError_t launch_compact_frames(const uint32_t* fcount, const uint2* fdet, uint32_t n_frames,
+                                 rsp_detection* list, uint32_t cap, uint32_t* counters,
+                                 uint32_t* d_count, hipStream_t stream);
 
 hipError_t launch_compact(const uint32_t* words, uint64_t n_cells, uint32_t log2_row,
                           uint32_t log2_rows_per_frame, rsp_detection* list, uint32_t cap,

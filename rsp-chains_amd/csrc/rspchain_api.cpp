@@ -74,7 +74,14 @@ struct rsp_chain {
   size_t d_out_bytes = 0;
   rsp_detection* d_list = nullptr;
   size_t d_list_cap = 0;
-  uint32_t* d_count = nullptr;
+  uint32_t* d_count = nullptr;   // [0] found (host-API path), [1] list cursor of the fused path
+  uint32_t* d_fcount = nullptr;  // per-frame peak counts of the fused path
+  uint2* d_fdet = nullptr;       // per-frame peak slots
+  size_t fslots = 0;             // frames the two buffers above hold
+  // per-launch HIP-event timing of the chain kernel alone (rsp_chain_profile_*)
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  size_t prof_used = 0;
 };
 
 namespace {
@@ -192,6 +199,7 @@ int check_regs(const rsp_chain* c) {
   if (R <= G) return fail(RSP_ERR_INVALID, "refWindowSize = %d must exceed guardWindowSize = %d", R, G);
   if (R > p.cfarParams.leadLaggWindowSize) return fail(RSP_ERR_INVALID, "refWindowSize = %d > leadLaggWindowSize = %d", R, p.cfarParams.leadLaggWindowSize);
   if (G > p.cfarParams.guardWindowSize) return fail(RSP_ERR_INVALID, "guardWindowSize = %d > elaborated maximum %d", G, p.cfarParams.guardWindowSize);
+  if (R + G > 256) return fail(RSP_ERR_UNSUPPORTED, "refWindowSize + guardWindowSize = %d exceeds the 256-cell LDS halo", R + G);
   if (2 * (R + G) + 1 > n) return fail(RSP_ERR_INVALID, "window 2*(%d+%d)+1 does not fit a %d-point frame", R, G, n);
   if (c->cfar[kMode] > 3) return fail(RSP_ERR_INVALID, "cfarMode register = %u", c->cfar[kMode]);
   if (c->cfar[kMode] == RSP_MODE_CASH) {
@@ -288,12 +296,24 @@ int ensure(void** ptr, size_t* have, size_t want) {
 
 size_t beat_bytes(const rsp_chain* c) { return c->p.dtype == RSP_DTYPE_F32 ? 8 : 4; }
 
-int launch_dense(rsp_chain* c, const void* d_in, size_t n_frames, uint32_t* d_out) {
+int launch_dense(rsp_chain* c, const void* d_in, size_t n_frames, uint32_t* d_out,
+                 rsp_detection* d_list = nullptr, uint32_t cap = 0, uint32_t* d_found = nullptr) {
   int rc = check_regs(c);
   if (rc != RSP_OK) return rc;
   if (n_frames > 0x7fffffffull) return fail(RSP_ERR_INVALID, "n_frames = %zu too large for one call", n_frames);
-  if (n_frames && (!d_in || !d_out)) return fail(RSP_ERR_INVALID, "NULL buffer");
+  if (n_frames && (!d_in || (!d_out && !d_found))) return fail(RSP_ERR_INVALID, "NULL buffer");
   HIP_TRY(hipSetDevice(c->device));
+  if (d_found && n_frames > c->fslots) {  // (re)size the per-frame slot buffers; not on the hot path
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_fcount) HIP_TRY(hipFree(c->d_fcount));
+    if (c->d_fdet) HIP_TRY(hipFree(c->d_fdet));
+    c->d_fcount = nullptr;
+    c->d_fdet = nullptr;
+    c->fslots = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_fcount), n_frames * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_fdet), n_frames * rsp::kFrameDetCap * sizeof(uint2)));
+    c->fslots = n_frames;
+  }
   rsp::Chain1dLaunch a{};
   a.in = d_in;
   a.out = d_out;
@@ -305,7 +325,30 @@ int launch_dense(rsp_chain* c, const void* d_in, size_t n_frames, uint32_t* d_ou
   if (rc != RSP_OK) return rc;
   a.log_lut = c->d_log_lut;
   a.stream = c->stream;
+  if (d_found) {
+    a.frame_count = c->d_fcount;
+    a.frame_det = c->d_fdet;
+    a.zero_a = c->d_count + 1;
+    a.zero_b = d_found;
+  }
+  hipEvent_t pe0 = nullptr, pe1 = nullptr;
+  if (c->profiling) {
+    if (c->prof_used == c->prof_events.size()) {
+      hipEvent_t e0, e1;
+      HIP_TRY(hipEventCreate(&e0));
+      HIP_TRY(hipEventCreate(&e1));
+      c->prof_events.emplace_back(e0, e1);
+    }
+    pe0 = c->prof_events[c->prof_used].first;
+    pe1 = c->prof_events[c->prof_used].second;
+    ++c->prof_used;
+    HIP_TRY(hipEventRecord(pe0, c->stream));
+  }
   HIP_TRY(rsp::launch_chain1d(a));
+  if (pe1) HIP_TRY(hipEventRecord(pe1, c->stream));
+  if (d_found)
+    HIP_TRY(rsp::launch_compact_frames(c->d_fcount, c->d_fdet, (uint32_t)n_frames, d_list, cap,
+                                       c->d_count + 1, d_found, c->stream));
   return RSP_OK;
 }
 
@@ -389,7 +432,7 @@ int rsp_chain_create(const rsp_chain_params* p, rsp_chain** out) {
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(RSP_ERR_DEVICE, "hipStreamCreate failed"));
   c->stream = c->own_stream;
   if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return bail(fail(RSP_ERR_DEVICE, "hipEventCreate failed"));
-  if (hipMalloc(reinterpret_cast<void**>(&c->d_count), sizeof(uint32_t)) != hipSuccess) return bail(fail(RSP_ERR_DEVICE, "hipMalloc failed"));
+  if (hipMalloc(reinterpret_cast<void**>(&c->d_count), 2 * sizeof(uint32_t)) != hipSuccess) return bail(fail(RSP_ERR_DEVICE, "hipMalloc failed"));
   if (p->dtype == RSP_DTYPE_FIXED16) {
     // log2 fraction table of the logMagMux (MAGParams log2LookUpWidth / binPointLog,
     // FftMagCfarChain.scala:95-96); entry f = round(log2(1 + f / 2^lw) * 2^bpLog)
@@ -416,6 +459,12 @@ void rsp_chain_destroy(rsp_chain* c) {
   if (c->d_out) (void)hipFree(c->d_out);
   if (c->d_list) (void)hipFree(c->d_list);
   if (c->d_count) (void)hipFree(c->d_count);
+  if (c->d_fcount) (void)hipFree(c->d_fcount);
+  if (c->d_fdet) (void)hipFree(c->d_fdet);
+  for (auto& pr : c->prof_events) {
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -468,6 +517,19 @@ int rsp_chain_process_device(rsp_chain* c, const void* d_in, size_t n_frames, ui
   return launch_dense(c, d_in, n_frames, d_out);
 }
 
+int rsp_chain_process_detect_device(rsp_chain* c, const void* d_in, size_t n_frames,
+                                    uint32_t* d_out_words, rsp_detection* d_list, uint32_t cap,
+                                    uint32_t* d_count) {
+  if (!c) return fail(RSP_ERR_INVALID, "chain is NULL");
+  if (!d_count || (cap && !d_list)) return fail(RSP_ERR_INVALID, "NULL buffer");
+  if (n_frames == 0) {
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), c->stream));
+    return RSP_OK;
+  }
+  return launch_dense(c, d_in, n_frames, d_out_words, d_list, cap, d_count);
+}
+
 int rsp_chain_process(rsp_chain* c, const void* in_beats, size_t n_frames, uint32_t* out_words) {
   if (!c) return fail(RSP_ERR_INVALID, "chain is NULL");
   int rc = check_regs(c);
@@ -512,16 +574,12 @@ int rsp_chain_process_detections(rsp_chain* c, const void* in_beats, size_t n_fr
   const size_t cells = n_frames << c->fft_stages;
   rc = ensure(&c->d_in, &c->d_in_bytes, cells * beat_bytes(c));
   if (rc != RSP_OK) return rc;
-  rc = ensure(reinterpret_cast<void**>(&c->d_out), &c->d_out_bytes, cells * sizeof(uint32_t));
-  if (rc != RSP_OK) return rc;
   size_t list_bytes = c->d_list_cap * sizeof(rsp_detection);
   rc = ensure(reinterpret_cast<void**>(&c->d_list), &list_bytes, std::max<size_t>(cap, 1) * sizeof(rsp_detection));
   if (rc != RSP_OK) return rc;
   c->d_list_cap = list_bytes / sizeof(rsp_detection);
   HIP_TRY(hipMemcpyAsync(c->d_in, in_beats, cells * beat_bytes(c), hipMemcpyHostToDevice, c->stream));
-  rc = launch_dense(c, c->d_in, n_frames, c->d_out);
-  if (rc != RSP_OK) return rc;
-  rc = rsp_chain_detections_device(c, c->d_out, n_frames, c->d_list, (uint32_t)cap, c->d_count);
+  rc = launch_dense(c, c->d_in, n_frames, nullptr, c->d_list, (uint32_t)cap, c->d_count);
   if (rc != RSP_OK) return rc;
   uint32_t found = 0;
   HIP_TRY(hipMemcpyAsync(&found, c->d_count, sizeof(found), hipMemcpyDeviceToHost, c->stream));
@@ -563,6 +621,29 @@ int rsp_chain_timer_stop(rsp_chain* c, float* elapsed_ms) {
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
   HIP_TRY(hipEventSynchronize(c->ev1));
   HIP_TRY(hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));
+  return RSP_OK;
+}
+
+int rsp_chain_profile_enable(rsp_chain* c, int on) {
+  if (!c) return fail(RSP_ERR_INVALID, "chain is NULL");
+  c->profiling = on != 0;
+  c->prof_used = 0;
+  return RSP_OK;
+}
+
+int rsp_chain_profile_read(rsp_chain* c, float* total_ms, uint32_t* launches) {
+  if (!c || !total_ms || !launches) return fail(RSP_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  float sum = 0.f;
+  for (size_t i = 0; i < c->prof_used; ++i) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->prof_events[i].first, c->prof_events[i].second));
+    sum += ms;
+  }
+  *total_ms = sum;
+  *launches = (uint32_t)c->prof_used;
+  c->prof_used = 0;
   return RSP_OK;
 }
 

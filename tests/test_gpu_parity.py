@@ -126,6 +126,41 @@ def test_empty_and_detections(gpu):
     assert np.array_equal(det["word"], dense[fr, bn])
 
 
+def test_fused_detection_list_matches_dense(gpu):
+    """rsp_chain_process_detect_device: the list emitted by the chain kernel equals the peaks of the
+    dense words, and the standalone compaction of those words gives the same set."""
+    n, frames = 1024, 37
+    params = make_params(n)
+    rt = R.RunTimeRspChainParams()
+    beats = tone_beats(frames, n, 900)
+    cap = 4096
+    with R.FftMagCfarChainVanilla(params) as dut:
+        dut.configure(rt)
+        d_in = R.DeviceBuffer(beats.nbytes); d_in.upload(beats)
+        d_out = R.DeviceBuffer(beats.size * 4)
+        d_list, d_cnt = R.DeviceBuffer(cap * 16), R.DeviceBuffer(8)
+        d_list2, d_cnt2 = R.DeviceBuffer(cap * 16), R.DeviceBuffer(8)
+        dut.process_detect_device(d_in.ptr, frames, d_out.ptr, d_list.ptr, cap, d_cnt.ptr)
+        dut.detections_device(d_out.ptr, frames, d_list2.ptr, cap, d_cnt2.ptr)
+        dut.synchronize()
+        dense = d_out.download(np.uint32, beats.size).reshape(frames, n)
+        found = int(d_cnt.download(np.uint32, 1)[0])
+        found2 = int(d_cnt2.download(np.uint32, 1)[0])
+        lst = d_list.download(np.uint32, found * 4).reshape(found, 4)
+        lst2 = d_list2.download(np.uint32, found2 * 4).reshape(found2, 4)
+        # list-only mode (no dense words)
+        dut.process_detect_device(d_in.ptr, frames, 0, d_list2.ptr, cap, d_cnt2.ptr)
+        dut.synchronize()
+        found3 = int(d_cnt2.download(np.uint32, 1)[0])
+        lst3 = d_list2.download(np.uint32, found3 * 4).reshape(found3, 4)
+    ref = O.chain_fixed(beats, oracle_cfg(params, rt)).reshape(frames, n)
+    assert np.array_equal(dense, ref)
+    fr, bn = np.nonzero(dense & 1)
+    want = sorted(zip(fr.tolist(), bn.tolist(), dense[fr, bn].tolist()))
+    for got in (lst, lst2, lst3):
+        assert sorted((int(a), int(b), int(w)) for a, b, _, w in got) == want
+
+
 @pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, 8192])
 def test_f32_all_sizes(gpu, n):
     params = make_params(n, dtype=R.F32, leadLagg=64)
@@ -145,7 +180,7 @@ def test_f32_all_sizes(gpu, n):
 @pytest.mark.parametrize("mag", [0, 1, 2])
 def test_f32_modes(gpu, mode, edge, mag):
     n = 2048
-    params = make_params(n, dtype=R.F32, edge=edge, leadLagg=256)
+    params = make_params(n, dtype=R.F32, edge=edge, leadLagg=128)
     rt = R.RunTimeRspChainParams(fftSize=n, CFARMode=mode, magMode=mag, refWindowSize=128, divSum=7,
                                  guardWindowSize=3, peakGrouping=1, logOrLinearMode=0 if mag == 1 else 1,
                                  thresholdScaler=2.0 if mag == 1 else 3.5)
