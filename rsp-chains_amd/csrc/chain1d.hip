@@ -107,10 +107,12 @@ template <>
 struct CfarMath<float> {
   static __device__ __forceinline__ float side(float sum, const ChainRegs& rg) { return sum * rg.div_f; }
   static __device__ __forceinline__ float half_sum(float a, float b) { return 0.5f * (a + b); }
+  // thr = stat * A + B with (A, B) = (scaler, 0) linear or (1, scaler) log: both exact
   static __device__ __forceinline__ uint32_t finish(float stat, float cut, bool group_ok, int k,
                                                     int log2n, const ChainRegs& rg) {
     (void)k; (void)log2n;
-    const float thr = rg.linear ? stat * rg.scaler_f : stat + rg.scaler_f;
+    const float A = rg.linear ? rg.scaler_f : 1.0f, B = rg.linear ? 0.0f : rg.scaler_f;
+    const float thr = __fmaf_rn(stat, A, B);
     const uint32_t peak = (cut > thr) && group_ok;
     return (__float_as_uint(thr) & ~1u) | peak;
   }
@@ -137,6 +139,14 @@ struct CfarMath<int> {
     return ((uint32_t)(int)thr << (log2n + 1)) | ((uint32_t)k << 1) | peak;
   }
 };
+
+// lane l receives the value of lane l - S of its 16-lane row, 0 for the first S lanes
+template <int S, typename V>
+__device__ __forceinline__ V row_shr(V v) {
+  static_assert(sizeof(V) == 4, "32-bit lanes");
+  const int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + S, 0xf, 0xf, true);
+  return __builtin_bit_cast(V, r);
+}
 
 // ---------------------------------------------------------------- the kernel
 
@@ -186,10 +196,18 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
       constexpr int W0 = plan_w(M, P - 1), LO0 = plan_lo(M, P - 1);
       constexpr int W1 = plan_w(M, P), LO1 = plan_lo(M, P);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) buf[pad(elem_index<M, LO0, W0>(tau, e))] = x[e];
+      for (int g = 0; g < (16 >> W0); ++g) {
+        f32x2* b0 = buf + slot_base<M, LO0, W0>(tau, g);
+#pragma unroll
+        for (int r = 0; r < (1 << W0); ++r) b0[slot_delta<LO0, W0>(r)] = x[g * (1 << W0) + r];
+      }
       __syncthreads();
 #pragma unroll
-      for (int e = 0; e < 16; ++e) x[e] = buf[pad(elem_index<M, LO1, W1>(tau, e))];
+      for (int g = 0; g < (16 >> W1); ++g) {
+        const f32x2* b1 = buf + slot_base<M, LO1, W1>(tau, g);
+#pragma unroll
+        for (int r = 0; r < (1 << W1); ++r) x[g * (1 << W1) + r] = b1[slot_delta<LO1, W1>(r)];
+      }
       pass_f32<M, P>(x, tau, twf);
     };
     exchange(std::integral_constant<int, 1>{});
@@ -220,14 +238,24 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
       constexpr int W0 = plan_w(M, P - 1), LO0 = plan_lo(M, P - 1);
       constexpr int W1 = plan_w(M, P), LO1 = plan_lo(M, P);
 #pragma unroll
-      for (int e = 0; e < 16; ++e)
-        buf[pad(elem_index<M, LO0, W0>(tau, e))] = ((uint32_t)xr[e] << 16) | ((uint32_t)xi[e] & 0xffffu);
+      for (int g = 0; g < (16 >> W0); ++g) {
+        uint32_t* b0 = buf + slot_base<M, LO0, W0>(tau, g);
+#pragma unroll
+        for (int r = 0; r < (1 << W0); ++r) {
+          const int e = g * (1 << W0) + r;
+          b0[slot_delta<LO0, W0>(r)] = ((uint32_t)xr[e] << 16) | ((uint32_t)xi[e] & 0xffffu);
+        }
+      }
       __syncthreads();
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const uint32_t b = buf[pad(elem_index<M, LO1, W1>(tau, e))];
-        xr[e] = (int)(short)(b >> 16);
-        xi[e] = (int)(short)(b & 0xffffu);
+      for (int g = 0; g < (16 >> W1); ++g) {
+        const uint32_t* b1 = buf + slot_base<M, LO1, W1>(tau, g);
+#pragma unroll
+        for (int r = 0; r < (1 << W1); ++r) {
+          const uint32_t b = b1[slot_delta<LO1, W1>(r)];
+          xr[g * (1 << W1) + r] = (int)(short)(b >> 16);
+          xi[g * (1 << W1) + r] = (int)(short)(b & 0xffffu);
+        }
       }
       pass_fx<M, P>(xr, xi, tau, twq, rg);
     };
@@ -247,11 +275,14 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
   const bool wrap = rg.edge != 0;
   __syncthreads();  // every thread is done reading the FFT image this overlays
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int g = e >> WL, p = e & ((1 << WL) - 1);
-    const int c = g * T + tau;
-    const int k = (bitrev_c(p, WL) << (M - WL)) | (int)(__brev((unsigned)c) >> (32 - (M - WL)));
-    mag[mag_slot(k)] = mg[e];
+  for (int g = 0; g < (16 >> WL); ++g) {
+    // bin = (q << (M-WL)) | bitrev(c): q << (M-WL) is a multiple of 16, so its slot offset is constant
+    V* mb = mag + mag_slot((int)(__brev((unsigned)(g * T + tau)) >> (32 - (M - WL))));
+#pragma unroll
+    for (int p = 0; p < (1 << WL); ++p) {
+      constexpr int QS = (1 << (M - WL)) + (1 << (M - WL - 4));
+      mb[bitrev_c(p, WL) * QS] = mg[g * (1 << WL) + p];
+    }
   }
   if (tau == 0) *det_cnt = 0u;
   __syncthreads();
@@ -269,14 +300,14 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
       loc[e] = acc;
       acc += v;
     }
-    V inc = acc;  // inclusive scan of chunk totals over the 16-lane row (= 256 cells)
-#pragma unroll
-    for (int d = 1; d < 16; d <<= 1) {
-      const V t = __shfl_up(inc, d, 16);
-      if ((tau & 15) >= d) inc += t;
-    }
-    V exc = __shfl_up(inc, 1, 16);
-    if ((tau & 15) == 0) exc = V(0);
+    // inclusive scan of chunk totals over the 16-lane DPP row (= 256 cells): row_shr shifts
+    // zeros in at the row start (bound_ctrl), so no lane masking is needed
+    V inc = acc;
+    inc += row_shr<1>(inc);
+    inc += row_shr<2>(inc);
+    inc += row_shr<4>(inc);
+    inc += row_shr<8>(inc);
+    const V exc = row_shr<1>(inc);
     const int p0 = pb_slot(16 * tau);
 #pragma unroll
     for (int e = 0; e < 16; ++e) pb[p0 + e] = exc + loc[e];
@@ -308,39 +339,83 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
   // ---- CFAR: cell k = tau + T j; window geometry FftMagCfarChain.scala:105-106 ----
   // lagging cells [k-G-R, k-G), leading cells [k+G+1, k+G+R+1); a window sum is
   // pb[v] - pb[u] (+ the total of u's block when the window crosses a block edge).
-  uint32_t* dst = (live && out) ? out + (size_t)frame * N : nullptr;
+  // The loop body is branch-free; cfarMode / peakGrouping are hoisted out of it.
+  uint32_t word[16];
   {
     const int R = rg.R, G = rg.G;
     const int xu0 = tau - G - R, xv0 = tau - G, xu1 = tau + G + 1, xv1 = tau + G + R + 1;
     constexpr int JS = T + T / 16;  // slot stride between a thread's consecutive cells
-    const int au0 = pb_slot(xu0), av0 = pb_slot(xv0), au1 = pb_slot(xu1), av1 = pb_slot(xv1);
-    const int am = mag_slot(tau);
+    const V* pu0 = pb + pb_slot(xu0);
+    const V* pv0 = pb + pb_slot(xv0);
+    const V* pu1 = pb + pb_slot(xu1);
+    const V* pv1 = pb + pb_slot(xv1);
+    const V* pm = mag + mag_slot(tau);
     // immediate neighbours (peak grouping): +-1 cell = +-1 slot, +-2 across a pad slot
     const int dl = ((tau & 15) == 0) ? 2 : 1, dr = ((tau & 15) == 15) ? 2 : 1;
+    auto cells = [&](auto mode_c, auto group_c) {
+      constexpr int MODE = decltype(mode_c)::value;
+      constexpr bool GROUP = decltype(group_c)::value;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int k = tau + T * j;
-      const int bu0 = (xu0 + T * j) >> 8, bu1 = (xu1 + T * j) >> 8;
-      const bool c0 = ((xv0 + T * j) >> 8) != bu0, c1 = ((xv1 + T * j) >> 8) != bu1;
-      V s0 = pb[av0 + JS * j] - pb[au0 + JS * j];
-      V s1 = pb[av1 + JS * j] - pb[au1 + JS * j];
-      const V f0 = bs[bu0], f1 = bs[bu1];
-      s0 += c0 ? f0 : V(0);
-      s1 += c1 ? f1 : V(0);
-      const V lagg = CfarMath<V>::side(s0, rg), lead = CfarMath<V>::side(s1, rg);
-      V stat;
-      if (rg.cfar_mode == 0) stat = CfarMath<V>::half_sum(lagg, lead);
-      else if (rg.cfar_mode == 1) stat = lagg > lead ? lagg : lead;
-      else stat = lagg < lead ? lagg : lead;
-      const V cut = mag[am + JS * j];
-      bool group_ok = true;
-      if (rg.peak_grouping) group_ok = cut > mag[am + JS * j - dl] && cut > mag[am + JS * j + dr];
-      const uint32_t word = CfarMath<V>::finish(stat, cut, group_ok, k, M, rg);
-      if (dst) dst[k] = word;
-      if (fcount && (word & 1u)) {
-        const uint32_t slot = atomicAdd(det_cnt, 1u);
-        if (slot < (uint32_t)kFrameDetCap) det_stage[slot] = make_uint2((uint32_t)k, word);
+      for (int j = 0; j < 16; ++j) {
+        int bu0, bu1;
+        bool c0, c1;
+        if constexpr (T % 256 == 0) {  // block of cell k is a per-thread constant + j T/256
+          bu0 = (xu0 >> 8) + j * (T / 256);
+          bu1 = (xu1 >> 8) + j * (T / 256);
+          c0 = (xv0 >> 8) != (xu0 >> 8);
+          c1 = (xv1 >> 8) != (xu1 >> 8);
+        } else {
+          bu0 = (xu0 + T * j) >> 8;
+          bu1 = (xu1 + T * j) >> 8;
+          c0 = ((xv0 + T * j) >> 8) != bu0;
+          c1 = ((xv1 + T * j) >> 8) != bu1;
+        }
+        V s0 = pv0[JS * j] - pu0[JS * j];
+        V s1 = pv1[JS * j] - pu1[JS * j];
+        const V f0 = bs[bu0], f1 = bs[bu1];
+        s0 += c0 ? f0 : V(0);
+        s1 += c1 ? f1 : V(0);
+        const V lagg = CfarMath<V>::side(s0, rg), lead = CfarMath<V>::side(s1, rg);
+        V stat;
+        if constexpr (MODE == 0) stat = CfarMath<V>::half_sum(lagg, lead);
+        else if constexpr (MODE == 1) stat = lagg > lead ? lagg : lead;
+        else stat = lagg < lead ? lagg : lead;
+        const V cut = pm[JS * j];
+        bool group_ok = true;
+        if constexpr (GROUP) group_ok = cut > pm[JS * j - dl] && cut > pm[JS * j + dr];
+        word[j] = CfarMath<V>::finish(stat, cut, group_ok, tau + T * j, M, rg);
       }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    if (rg.peak_grouping) {
+      if (rg.cfar_mode == 0) cells(I0{}, std::true_type{});
+      else if (rg.cfar_mode == 1) cells(I1{}, std::true_type{});
+      else cells(I2{}, std::true_type{});
+    } else {
+      if (rg.cfar_mode == 0) cells(I0{}, std::false_type{});
+      else if (rg.cfar_mode == 1) cells(I1{}, std::false_type{});
+      else cells(I2{}, std::false_type{});
+    }
+  }
+  if (live && out) {
+    uint32_t* dst = out + (size_t)frame * N + tau;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dst[T * j] = word[j];
+  }
+  if (fcount) {
+    uint32_t hits = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) hits |= (word[j] & 1u) << j;
+    while (hits) {  // rare: ~1 peak per 1000 cells
+      const int j = __ffs(hits) - 1;
+      hits &= hits - 1;
+      uint32_t w = word[0];
+#pragma unroll
+      for (int q = 1; q < 16; ++q) w = (j == q) ? word[q] : w;
+      const uint32_t slot = atomicAdd(det_cnt, 1u);
+      if (slot < (uint32_t)kFrameDetCap) det_stage[slot] = make_uint2((uint32_t)(tau + T * j), w);
     }
   }
 

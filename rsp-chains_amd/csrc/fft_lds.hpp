@@ -69,6 +69,21 @@ __device__ __forceinline__ int elem_index(int tau, int e) {
   return (high << (LO + W)) | (r << LO) | low;
 }
 
+// LDS slot of that sample = slot_base(tau, g) + slot_delta(r): pad() is additive across the
+// field bits (no carry can cross them), so the per-register part is a compile-time constant
+// that folds into the ds_read/ds_write offset field.
+template <int M, int LO, int W>
+__device__ __forceinline__ int slot_base(int tau, int g) {
+  constexpr int T = threads_per_frame(M);
+  const int c = g * T + tau;
+  const int i0 = ((c >> LO) << (LO + W)) | (c & ((1 << LO) - 1));
+  return pad(i0);
+}
+template <int LO, int W>
+__host__ __device__ constexpr int slot_delta(int r) {
+  return (r << LO) + ((r << LO) >> 4);
+}
+
 __host__ __device__ constexpr int bitrev_c(int x, int bits) {
   int r = 0;
   for (int i = 0; i < bits; ++i) r |= ((x >> i) & 1) << (bits - 1 - i);
@@ -77,11 +92,11 @@ __host__ __device__ constexpr int bitrev_c(int x, int bits) {
 
 // ---------------------------------------------------------------- F32 pieces
 
+// (ax wx - ay wy, ax wy + ay wx) as v_pk_mul_f32 + v_pk_fma_f32: the broadcasts, the
+// swap and the negation are op_sel / neg_lo operand modifiers, not instructions.
 __device__ __forceinline__ f32x2 cmul(f32x2 a, f32x2 w) {
-  f32x2 r;
-  r.x = a.x * w.x - a.y * w.y;
-  r.y = a.x * w.y + a.y * w.x;
-  return r;
+  const f32x2 axx = {a.x, a.x}, ayy = {a.y, a.y}, wyx = {-w.y, w.x};
+  return __builtin_elementwise_fma(ayy, wyx, axx * w);
 }
 
 // d * exp(-2 pi i k16 / 16), k16 a compile-time constant after unrolling
