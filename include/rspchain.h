@@ -197,7 +197,7 @@ int rsp_chain_process_detections(rsp_chain* c, const void* in_beats, size_t n_fr
                                  rsp_detection* list, size_t cap, size_t* n_found);
 
 /* --- stream / memory / timing plumbing -------------------------------------- */
-/* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores
+/* Run on a caller-owned hipStream_t (e.g. the stream a host framework is already using); NULL restores
  * the chain's own stream. */
 int rsp_chain_set_stream(rsp_chain* c, void* hip_stream);
 int rsp_chain_synchronize(rsp_chain* c);

@@ -12,6 +12,8 @@ from .chain import (  # noqa: F401
     MAGParams, RspError, RunTimeRspChainParams, device_count, isPow2, log2Up, unpack_output,
     unpack_output_f32)
 from . import stimulus  # noqa: F401
+from . import dist  # noqa: F401
+from . import dumps  # noqa: F401
 
 __all__ = [n for n in dir() if not n.startswith("_")]
 

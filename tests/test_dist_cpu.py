@@ -1,0 +1,59 @@
+"""N > 1 path on CPU: two gloo ranks shard the frames, each produces its detection list (here
+from the oracle standing in for the GPU kernel), and the lists are all-gathered by the same
+code the GPU bench uses over RCCL."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np
+    import torch, torch.distributed as dist
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+    import rsp_chains_amd as R
+    from rsp_chains_amd.dist import shard_range, gather_detections, merge_gathered
+    from oracle import oracle as O
+    from helpers import make_params, oracle_cfg, tone_beats
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n, frames, cap = 256, 11, 64
+    params = make_params(n); rt = R.RunTimeRspChainParams(fftSize=n, refWindowSize=16, divSum=4)
+    beats = tone_beats(frames, n, 4242)
+    lo, hi = shard_range(frames, rank, world)
+    words = O.chain_fixed(beats[lo:hi], oracle_cfg(params, rt)).reshape(hi - lo, n)
+    fr, bn = np.nonzero(words & 1)
+    lst = np.zeros((cap, 4), np.int32)
+    k = len(fr)
+    lst[:k, 0], lst[:k, 1], lst[:k, 3] = fr, bn, words[fr, bn].astype(np.int64).astype(np.int32)
+    lists, counts = gather_detections(torch.from_numpy(lst), torch.tensor([k], dtype=torch.int32), cap)
+    firsts = [shard_range(frames, r, world)[0] for r in range(world)]
+    merged = merge_gathered(lists, counts, firsts)
+    full = O.chain_fixed(beats, oracle_cfg(params, rt)).reshape(frames, n)
+    gfr, gbn = np.nonzero(full & 1)
+    want = sorted(zip(gfr.tolist(), gbn.tolist()))
+    got = sorted(zip(merged[:, 0].tolist(), merged[:, 1].tolist()))
+    assert got == want, (rank, got[:5], want[:5])
+    assert int(counts.sum()) == len(want)
+    dist.barrier(); dist.destroy_process_group()
+    print("rank", rank, "ok", len(want))
+""")
+
+
+def test_two_rank_gloo_shard_and_gather(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count("ok") == 2  # both ranks (their prints may interleave)

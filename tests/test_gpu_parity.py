@@ -211,3 +211,23 @@ def test_f32_linearity_full_batch(gpu):
     assert np.array_equal(ta * np.float32(0.125), tb)
     # identical frames give identical rows (no cross-frame state)
     assert np.array_equal(a[:64], a[64:128])
+
+
+def test_cpp_host_tester_replays_dumps(gpu, tmp_path):
+    """The C++ host mirror (host/RspChain.hpp) run as the reference tester: reads the tester's
+    input dumps, writes outputData.txt; must equal the Python host path and the oracle."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host = os.path.join(root, "rsp-chains_amd", "host")
+    subprocess.run(["make", "-C", host], check=True, stdout=subprocess.DEVNULL)
+    n = 1024
+    z = R.stimulus.getComplexTones(n, 0.125, 0.25, 0.5, shiftRangeFactor=12, seed=777)
+    R.dumps.write_input_dumps(str(tmp_path), z)
+    out = subprocess.run([os.path.join(host, "tester"), str(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "peaks 4" in out.stdout
+    got = R.dumps.read_output_words(str(tmp_path))
+    params, rt = make_params(n), R.RunTimeRspChainParams()
+    ref = O.chain_fixed(R.stimulus.formAXI4StreamComplexData(z), oracle_cfg(params, rt))
+    assert np.array_equal(got, ref)
