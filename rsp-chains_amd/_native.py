@@ -10,7 +10,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librspchain.so")
+# RSP_CHAIN_LIB: A/B-time an alternative build of the same ABI (tools/ab.sh); never a fallback
+LIB_PATH = os.environ.get("RSP_CHAIN_LIB") or os.path.join(_HERE, "librspchain.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 RSP_MAX_STAGES = 16
@@ -100,7 +101,7 @@ def build(force: bool = False) -> str:
 
 
 def _stale() -> bool:
-    if not os.path.isdir(CSRC):
+    if os.environ.get("RSP_CHAIN_LIB") or not os.path.isdir(CSRC):
         return False
     t = os.path.getmtime(LIB_PATH)
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".hpp"))]

@@ -14,6 +14,7 @@
 // long-range cancellation for fp32.
 #include <hip/hip_runtime.h>
 #include <float.h>
+#include <stdlib.h>
 
 #include "chain_regs.hpp"
 #include "fft_lds.hpp"
@@ -177,16 +178,19 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
 
   if constexpr (!FIXED) {
     f32x2* buf = reinterpret_cast<f32x2*>(fbase);
-    const f32x2* src = reinterpret_cast<const f32x2*>(in) + (size_t)frame * N;
     const f32x2* twf = reinterpret_cast<const f32x2*>(tw);
     f32x2 x[16];
     {
       constexpr int W = plan_w(M, 0), LO = plan_lo(M, 0);
+      // uniform base (SGPR pair) + one 32-bit per-thread byte offset; the per-register part is a
+      // compile-time constant (the launcher keeps one launch's input below 4 GiB)
+      const char* gbase = reinterpret_cast<const char*>(in);
+      // a dead frame (ragged last workgroup) re-reads frame 0 and never stores
+      const uint32_t voff = ((live ? frame : 0u) * (uint32_t)N + (uint32_t)elem_index<M, LO, W>(tau, 0)) * 8u;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        f32x2 z = {0.f, 0.f};
-        if (live) z = src[elem_index<M, LO, W>(tau, e)];
-        x[e] = z;
+        const size_t eo = (size_t)(elem_index<M, LO, W>(0, e) - elem_index<M, LO, W>(0, 0)) * 8u;
+        x[e] = *reinterpret_cast<const f32x2*>(gbase + (size_t)voff + eo);
       }
     }
     pass_f32<M, 0>(x, tau, twf);
@@ -214,20 +218,30 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
     if constexpr (NP > 2) exchange(std::integral_constant<int, 2>{});
     if constexpr (NP > 3) exchange(std::integral_constant<int, 3>{});
     const float scale = 1.0f / (float)N;  // net 1/N: FftMagCfarChainTester.scala:77
+    // mode select hoisted out of the per-bin loop (a uniform branch per bin costs ~15 SALU each)
+    if (rg.mag_mode == 2) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) mg[e] = mag_f32(x[e] * scale, rg.mag_mode);
+      for (int e = 0; e < 16; ++e) mg[e] = mag_f32(x[e] * scale, 2);
+    } else if (rg.mag_mode == 0) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mg[e] = mag_f32(x[e] * scale, 0);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mg[e] = mag_f32(x[e] * scale, 1);
+    }
   } else {
     uint32_t* buf = reinterpret_cast<uint32_t*>(fbase);
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(in) + (size_t)frame * N;
     const uint32_t* twq = reinterpret_cast<const uint32_t*>(tw);
     int xr[16], xi[16];
     {
       constexpr int W = plan_w(M, 0), LO = plan_lo(M, 0);
+      const char* gbase = reinterpret_cast<const char*>(in);
+      const uint32_t voff = ((live ? frame : 0u) * (uint32_t)N + (uint32_t)elem_index<M, LO, W>(tau, 0)) * 4u;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         // beat = {re[31:16], im[15:0]}: RspChainTesterUtils.scala:105-109
-        uint32_t b = 0;
-        if (live) b = src[elem_index<M, LO, W>(tau, e)];
+        const size_t eo = (size_t)(elem_index<M, LO, W>(0, e) - elem_index<M, LO, W>(0, 0)) * 4u;
+        const uint32_t b = *reinterpret_cast<const uint32_t*>(gbase + (size_t)voff + eo);
         xr[e] = (int)(short)(b >> 16);
         xi[e] = (int)(short)(b & 0xffffu);
       }
@@ -262,8 +276,13 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
     exchange(std::integral_constant<int, 1>{});
     if constexpr (NP > 2) exchange(std::integral_constant<int, 2>{});
     if constexpr (NP > 3) exchange(std::integral_constant<int, 3>{});
+    if (rg.mag_mode == 2) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) mg[e] = mag_fx(xr[e], xi[e], rg, log_lut);
+      for (int e = 0; e < 16; ++e) mg[e] = jpl_fx(xr[e], xi[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mg[e] = mag_fx(xr[e], xi[e], rg, log_lut);
+    }
   }
 
   // ---- magnitudes to LDS in natural bin order ----
@@ -352,6 +371,8 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
     const V* pm = mag + mag_slot(tau);
     // immediate neighbours (peak grouping): +-1 cell = +-1 slot, +-2 across a pad slot
     const int dl = ((tau & 15) == 0) ? 2 : 1, dr = ((tau & 15) == 15) ? 2 : 1;
+    // F32 threshold = comb * kA + kB: (div * scaler, 0) linear, (div, scaler) log domain
+    const float kA = rg.linear ? rg.div_f * rg.scaler_f : rg.div_f, kB = rg.linear ? 0.0f : rg.scaler_f;
     auto cells = [&](auto mode_c, auto group_c) {
       constexpr int MODE = decltype(mode_c)::value;
       constexpr bool GROUP = decltype(group_c)::value;
@@ -370,20 +391,35 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
           c0 = ((xv0 + T * j) >> 8) != bu0;
           c1 = ((xv1 + T * j) >> 8) != bu1;
         }
-        V s0 = pv0[JS * j] - pu0[JS * j];
-        V s1 = pv1[JS * j] - pu1[JS * j];
-        const V f0 = bs[bu0], f1 = bs[bu1];
-        s0 += c0 ? f0 : V(0);
-        s1 += c1 ? f1 : V(0);
-        const V lagg = CfarMath<V>::side(s0, rg), lead = CfarMath<V>::side(s1, rg);
-        V stat;
-        if constexpr (MODE == 0) stat = CfarMath<V>::half_sum(lagg, lead);
-        else if constexpr (MODE == 1) stat = lagg > lead ? lagg : lead;
-        else stat = lagg < lead ? lagg : lead;
         const V cut = pm[JS * j];
         bool group_ok = true;
         if constexpr (GROUP) group_ok = cut > pm[JS * j - dl] && cut > pm[JS * j + dr];
-        word[j] = CfarMath<V>::finish(stat, cut, group_ok, tau + T * j, M, rg);
+        if constexpr (!FIXED) {
+          // both windows in one packed subtract / fma; divSum, the 1/2 of CA and the scaler are
+          // folded into kA (powers of two except the scaler: the same single rounding as the spec)
+          const f32x2 pv = {pv0[JS * j], pv1[JS * j]}, pu = {pu0[JS * j], pu1[JS * j]};
+          const f32x2 ff = {bs[bu0], bs[bu1]}, cm = {c0 ? 1.0f : 0.0f, c1 ? 1.0f : 0.0f};
+          const f32x2 sw = __builtin_elementwise_fma(cm, ff, pv - pu);
+          float comb;
+          if constexpr (MODE == 0) comb = sw.x + sw.y;
+          else if constexpr (MODE == 1) comb = fmaxf(sw.x, sw.y);
+          else comb = fminf(sw.x, sw.y);
+          const float thr = __fmaf_rn(comb, MODE == 0 ? kA * 0.5f : kA, kB);
+          const uint32_t peak = (cut > thr) && group_ok;
+          word[j] = (__float_as_uint(thr) & ~1u) | peak;
+        } else {
+          V s0 = pv0[JS * j] - pu0[JS * j];
+          V s1 = pv1[JS * j] - pu1[JS * j];
+          const V f0 = bs[bu0], f1 = bs[bu1];
+          s0 += c0 ? f0 : V(0);
+          s1 += c1 ? f1 : V(0);
+          const V lagg = CfarMath<V>::side(s0, rg), lead = CfarMath<V>::side(s1, rg);
+          V stat;
+          if constexpr (MODE == 0) stat = CfarMath<V>::half_sum(lagg, lead);
+          else if constexpr (MODE == 1) stat = lagg > lead ? lagg : lead;
+          else stat = lagg < lead ? lagg : lead;
+          word[j] = CfarMath<V>::finish(stat, cut, group_ok, tau + T * j, M, rg);
+        }
       }
     };
     using I0 = std::integral_constant<int, 0>;
@@ -400,9 +436,11 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
     }
   }
   if (live && out) {
-    uint32_t* dst = out + (size_t)frame * N + tau;
+    char* obase = reinterpret_cast<char*>(out);
+    const uint32_t ooff = (frame * (uint32_t)N + (uint32_t)tau) * 4u;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) dst[T * j] = word[j];
+    for (int j = 0; j < 16; ++j)
+      *reinterpret_cast<uint32_t*>(obase + (size_t)ooff + (size_t)(T * j) * 4u) = word[j];
   }
   if (fcount) {
     uint32_t hits = 0;
@@ -437,7 +475,8 @@ template <int M>
 static hipError_t launch_m(const Chain1dLaunch& a) {
   const uint32_t fpw = frames_per_wg(M);
   const uint32_t grid = (a.n_frames + fpw - 1) / fpw;
-  const size_t lds = FrameLds<M>::BYTES * fpw;
+  size_t lds = FrameLds<M>::BYTES * fpw;
+  if (const char* ex = getenv("RSP_DEBUG_EXTRA_LDS")) lds += (size_t)atoi(ex);  // occupancy experiments only
   if (a.fixed) {
     auto k = chain1d_kernel<M, true>;
     if (lds > 48 * 1024) {
@@ -460,17 +499,32 @@ static hipError_t launch_m(const Chain1dLaunch& a) {
   return hipGetLastError();
 }
 
-hipError_t launch_chain1d(const Chain1dLaunch& a) {
-  if (a.n_frames == 0) return hipSuccess;
-  switch (a.log2n) {
-    case 8: return launch_m<8>(a);
-    case 9: return launch_m<9>(a);
-    case 10: return launch_m<10>(a);
-    case 11: return launch_m<11>(a);
-    case 12: return launch_m<12>(a);
-    case 13: return launch_m<13>(a);
-    default: return hipErrorInvalidValue;
+hipError_t launch_chain1d(const Chain1dLaunch& a0) {
+  if (a0.n_frames == 0) return hipSuccess;
+  // kernels address a launch's input with 32-bit byte offsets: split into < 4 GiB pieces
+  const uint64_t beat = a0.fixed ? 4 : 8;
+  const uint32_t max_frames = (uint32_t)((0xFFFFFFFFull / (beat << a0.log2n)) & ~63ull);
+  Chain1dLaunch a = a0;
+  for (uint32_t done = 0; done < a0.n_frames; done += max_frames) {
+    a.n_frames = a0.n_frames - done < max_frames ? a0.n_frames - done : max_frames;
+    a.in = static_cast<const char*>(a0.in) + ((uint64_t)done << a0.log2n) * beat;
+    a.out = a0.out ? a0.out + ((uint64_t)done << a0.log2n) : nullptr;
+    a.frame_count = a0.frame_count ? a0.frame_count + done : nullptr;
+    a.frame_det = a0.frame_det ? a0.frame_det + (uint64_t)done * kFrameDetCap : nullptr;
+    if (done) a.zero_a = a.zero_b = nullptr;
+    hipError_t e;
+    switch (a.log2n) {
+      case 8: e = launch_m<8>(a); break;
+      case 9: e = launch_m<9>(a); break;
+      case 10: e = launch_m<10>(a); break;
+      case 11: e = launch_m<11>(a); break;
+      case 12: e = launch_m<12>(a); break;
+      case 13: e = launch_m<13>(a); break;
+      default: return hipErrorInvalidValue;
+    }
+    if (e != hipSuccess) return e;
   }
+  return hipSuccess;
 }
 
 // ---------------------------------------------------------------- detection compaction
