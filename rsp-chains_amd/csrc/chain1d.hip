@@ -22,6 +22,14 @@
 
 namespace rsp {
 
+// -DRSP_ABLATE builds (tools/ablate.sh) read a phase mask from ChainRegs::sub_window (unused by
+// the CA-family kernel) to switch phases off at run time; production builds compile it away.
+#ifdef RSP_ABLATE
+#define ABL(bit) (rg.sub_window & (1 << (bit)))
+#else
+#define ABL(bit) false
+#endif
+
 // ---------------------------------------------------------------- LDS layout per frame
 // After the FFT the frame's LDS is re-used for the CFAR working set (4-byte slots):
 //   mag : cell x in [-16, N+16)   at slot pad(x + 16)    (1-cell halo for peak grouping)
@@ -193,33 +201,40 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
         x[e] = *reinterpret_cast<const f32x2*>(gbase + (size_t)voff + eo);
       }
     }
-    pass_f32<M, 0>(x, tau, twf);
+    if (!ABL(0)) pass_f32<M, 0>(x, tau, twf);
     // passes 1..NP-1 through LDS
     auto exchange = [&](auto pc) {
       constexpr int P = decltype(pc)::value;
       constexpr int W0 = plan_w(M, P - 1), LO0 = plan_lo(M, P - 1);
       constexpr int W1 = plan_w(M, P), LO1 = plan_lo(M, P);
+      if (!ABL(3)) {
 #pragma unroll
       for (int g = 0; g < (16 >> W0); ++g) {
         f32x2* b0 = buf + slot_base<M, LO0, W0>(tau, g);
 #pragma unroll
         for (int r = 0; r < (1 << W0); ++r) b0[slot_delta<LO0, W0>(r)] = x[g * (1 << W0) + r];
       }
+      }
       __syncthreads();
+      if (!ABL(3)) {
 #pragma unroll
       for (int g = 0; g < (16 >> W1); ++g) {
         const f32x2* b1 = buf + slot_base<M, LO1, W1>(tau, g);
 #pragma unroll
         for (int r = 0; r < (1 << W1); ++r) x[g * (1 << W1) + r] = b1[slot_delta<LO1, W1>(r)];
       }
-      pass_f32<M, P>(x, tau, twf);
+      }
+      if (!ABL(0)) pass_f32<M, P>(x, tau, twf);
     };
     exchange(std::integral_constant<int, 1>{});
     if constexpr (NP > 2) exchange(std::integral_constant<int, 2>{});
     if constexpr (NP > 3) exchange(std::integral_constant<int, 3>{});
     const float scale = 1.0f / (float)N;  // net 1/N: FftMagCfarChainTester.scala:77
     // mode select hoisted out of the per-bin loop (a uniform branch per bin costs ~15 SALU each)
-    if (rg.mag_mode == 2) {
+    if (ABL(4)) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mg[e] = x[e].x;
+    } else if (rg.mag_mode == 2) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) mg[e] = mag_f32(x[e] * scale, 2);
     } else if (rg.mag_mode == 0) {
@@ -307,7 +322,7 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
   __syncthreads();
 
   // ---- block-relative exclusive prefix sums: thread owns cells 16 tau .. 16 tau + 15 ----
-  {
+  if (!ABL(2)) {
     V loc[16];
     V acc = V(0), first = V(0), last = V(0);
     const int m0 = mag_slot(16 * tau);  // the 16-cell chunk is contiguous in LDS
@@ -425,7 +440,10 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
-    if (rg.peak_grouping) {
+    if (ABL(1)) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) word[j] = __builtin_bit_cast(uint32_t, pm[JS * j]);
+    } else if (rg.peak_grouping) {
       if (rg.cfar_mode == 0) cells(I0{}, std::true_type{});
       else if (rg.cfar_mode == 1) cells(I1{}, std::true_type{});
       else cells(I2{}, std::true_type{});

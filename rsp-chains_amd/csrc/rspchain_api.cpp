@@ -246,6 +246,9 @@ rsp::ChainRegs snapshot(const rsp_chain* c) {
   r.idx_lagg = (int)c->cfar[kIndexLagg];
   r.idx_lead = (int)c->cfar[kIndexLead];
   r.sub_window = (int)c->cfar[kSubWindow];
+#ifdef RSP_ABLATE
+  if (const char* m = getenv("RSP_ABLATE_MASK")) r.sub_window = atoi(m);
+#endif
   r.edge = p.cfarParams.edgeMode;
   return r;
 }
