@@ -159,31 +159,15 @@ __device__ __forceinline__ V row_shr(V v) {
 
 // ---------------------------------------------------------------- the kernel
 
-template <int M, bool FIXED>
-__global__ void __launch_bounds__(wg_size(M))
-chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t n_frames,
-               ChainRegs rg, const void* __restrict__ tw, const int16_t* __restrict__ log_lut,
-               uint32_t* __restrict__ fcount, uint2* __restrict__ fdet,
-               uint32_t* __restrict__ zero_a, uint32_t* __restrict__ zero_b) {
-  constexpr int N = 1 << M, T = threads_per_frame(M), FPW = frames_per_wg(M), NP = plan_np(M);
-  // counters of the compaction launch that follows on this stream (saves two memset nodes)
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (zero_a) *zero_a = 0u;
-    if (zero_b) *zero_b = 0u;
-  }
-  using L = FrameLds<M>;
-  using V = typename std::conditional<FIXED, int, float>::type;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-  const int tid = threadIdx.x;
-  const int fl = tid / T, tau = tid % T;
-  const uint32_t frame = blockIdx.x * FPW + fl;
-  const bool live = frame < n_frames;  // dead frames still walk every barrier
-  unsigned char* fbase = smem + fl * L::BYTES;
-
-  V mg[16];  // magnitudes of this thread's 16 bins, bin = (q << (M-WL)) | bitrev(c)
-  constexpr int WL = plan_w(M, NP - 1);
-
+// ---------------------------------------------------------------- shared front end
+// Frame -> FFT (passes through LDS at fbase) -> magnitude of this thread's 16 bins in registers:
+// mg[g * 2^WL + p] is bin (bitrev(p) << (M - WL)) | bitrev(g T + tau).
+template <int M, bool FIXED, typename V>
+__device__ __forceinline__ void front_end(const void* __restrict__ in, uint32_t frame, bool live, int tau,
+                                          unsigned char* fbase, const ChainRegs& rg,
+                                          const void* __restrict__ tw,
+                                          const int16_t* __restrict__ log_lut, V (&mg)[16]) {
+  constexpr int N = 1 << M, NP = plan_np(M);
   if constexpr (!FIXED) {
     f32x2* buf = reinterpret_cast<f32x2*>(fbase);
     const f32x2* twf = reinterpret_cast<const f32x2*>(tw);
@@ -300,6 +284,87 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
     }
   }
 
+}
+
+// magnitudes -> LDS in natural bin order, cell x at slot pad(x + moff) (moff a multiple of 16)
+template <int M, typename V>
+__device__ __forceinline__ void write_mag(V* mag, int moff, int tau, const V (&mg)[16]) {
+  constexpr int T = threads_per_frame(M), NP = plan_np(M), WL = plan_w(M, NP - 1);
+#pragma unroll
+  for (int g = 0; g < (16 >> WL); ++g) {
+    // bin = (q << (M-WL)) | bitrev(c): q << (M-WL) is a multiple of 16, so its slot offset is constant
+    V* mb = mag + pad((int)(__brev((unsigned)(g * T + tau)) >> (32 - (M - WL))) + moff);
+#pragma unroll
+    for (int p = 0; p < (1 << WL); ++p) {
+      constexpr int QS = (1 << (M - WL)) + (1 << (M - WL - 4));
+      mb[bitrev_c(p, WL) * QS] = mg[g * (1 << WL) + p];
+    }
+  }
+}
+
+// dense words to HBM (256 B per wave-instruction) + optional per-frame detection slots
+template <int M>
+__device__ __forceinline__ void emit_words(const uint32_t (&word)[16], uint32_t* __restrict__ out,
+                                           uint32_t frame, bool live, int tau, uint32_t* det_cnt,
+                                           uint2* det_stage, uint32_t* __restrict__ fcount,
+                                           uint2* __restrict__ fdet) {
+  constexpr int N = 1 << M, T = threads_per_frame(M);
+  if (live && out) {
+    char* obase = reinterpret_cast<char*>(out);
+    const uint32_t ooff = (frame * (uint32_t)N + (uint32_t)tau) * 4u;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      *reinterpret_cast<uint32_t*>(obase + (size_t)ooff + (size_t)(T * j) * 4u) = word[j];
+  }
+  if (fcount) {
+    uint32_t hits = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) hits |= (word[j] & 1u) << j;
+    while (hits) {  // rare: ~1 peak per 1000 cells
+      const int j = __ffs(hits) - 1;
+      hits &= hits - 1;
+      uint32_t w = word[0];
+#pragma unroll
+      for (int q = 1; q < 16; ++q) w = (j == q) ? word[q] : w;
+      const uint32_t slot = atomicAdd(det_cnt, 1u);
+      if (slot < (uint32_t)kFrameDetCap) det_stage[slot] = make_uint2((uint32_t)(tau + T * j), w);
+    }
+    // per-frame detection slots (no global atomics): count + first kFrameDetCap peaks
+    __syncthreads();
+    if (live) {
+      const uint32_t cnt = *det_cnt;
+      if (tau == 0) fcount[frame] = cnt;
+      for (uint32_t i = tau; i < min(cnt, (uint32_t)kFrameDetCap); i += T)
+        fdet[(size_t)frame * kFrameDetCap + i] = det_stage[i];
+    }
+  }
+}
+
+template <int M, bool FIXED>
+__global__ void __launch_bounds__(wg_size(M))
+chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t n_frames,
+               ChainRegs rg, const void* __restrict__ tw, const int16_t* __restrict__ log_lut,
+               uint32_t* __restrict__ fcount, uint2* __restrict__ fdet,
+               uint32_t* __restrict__ zero_a, uint32_t* __restrict__ zero_b) {
+  constexpr int N = 1 << M, T = threads_per_frame(M), FPW = frames_per_wg(M), NP = plan_np(M);
+  // counters of the compaction launch that follows on this stream (saves two memset nodes)
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (zero_a) *zero_a = 0u;
+    if (zero_b) *zero_b = 0u;
+  }
+  using L = FrameLds<M>;
+  using V = typename std::conditional<FIXED, int, float>::type;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int fl = tid / T, tau = tid % T;
+  const uint32_t frame = blockIdx.x * FPW + fl;
+  const bool live = frame < n_frames;  // dead frames still walk every barrier
+  unsigned char* fbase = smem + fl * L::BYTES;
+
+  V mg[16];
+  front_end<M, FIXED, V>(in, frame, live, tau, fbase, rg, tw, log_lut, mg);
+
   // ---- magnitudes to LDS in natural bin order ----
   V* mag = reinterpret_cast<V*>(fbase + L::MAG_OFF);
   V* pb = reinterpret_cast<V*>(fbase + L::PB_OFF);
@@ -308,16 +373,7 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
   uint2* det_stage = reinterpret_cast<uint2*>(fbase + L::DET_OFF + 8);
   const bool wrap = rg.edge != 0;
   __syncthreads();  // every thread is done reading the FFT image this overlays
-#pragma unroll
-  for (int g = 0; g < (16 >> WL); ++g) {
-    // bin = (q << (M-WL)) | bitrev(c): q << (M-WL) is a multiple of 16, so its slot offset is constant
-    V* mb = mag + mag_slot((int)(__brev((unsigned)(g * T + tau)) >> (32 - (M - WL))));
-#pragma unroll
-    for (int p = 0; p < (1 << WL); ++p) {
-      constexpr int QS = (1 << (M - WL)) + (1 << (M - WL - 4));
-      mb[bitrev_c(p, WL) * QS] = mg[g * (1 << WL) + p];
-    }
-  }
+  write_mag<M, V>(mag, 16, tau, mg);
   if (tau == 0) *det_cnt = 0u;
   __syncthreads();
 
@@ -453,44 +509,221 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
       else cells(I2{}, std::false_type{});
     }
   }
-  if (live && out) {
-    char* obase = reinterpret_cast<char*>(out);
-    const uint32_t ooff = (frame * (uint32_t)N + (uint32_t)tau) * 4u;
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-      *reinterpret_cast<uint32_t*>(obase + (size_t)ooff + (size_t)(T * j) * 4u) = word[j];
-  }
-  if (fcount) {
-    uint32_t hits = 0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) hits |= (word[j] & 1u) << j;
-    while (hits) {  // rare: ~1 peak per 1000 cells
-      const int j = __ffs(hits) - 1;
-      hits &= hits - 1;
-      uint32_t w = word[0];
-#pragma unroll
-      for (int q = 1; q < 16; ++q) w = (j == q) ? word[q] : w;
-      const uint32_t slot = atomicAdd(det_cnt, 1u);
-      if (slot < (uint32_t)kFrameDetCap) det_stage[slot] = make_uint2((uint32_t)(tau + T * j), w);
-    }
-  }
+  emit_words<M>(word, out, frame, live, tau, det_cnt, det_stage, fcount, fdet);
+}
 
-  // ---- per-frame detection slots (no global atomics): count + first kFrameDetCap peaks ----
-  if (fcount) {
-    __syncthreads();
-    if (live) {
-      const uint32_t cnt = *det_cnt;
-      if (tau == 0) fcount[frame] = cnt;
-      for (uint32_t i = tau; i < min(cnt, (uint32_t)kFrameDetCap); i += T)
-        fdet[(size_t)frame * kFrameDetCap + i] = det_stage[i];
+// ---------------------------------------------------------------- GOS / ordered-statistic CFAR
+// GOSCFARType / GOSCACFARType with cfarAlgorithm = GOS (FftMagCfarChainTester.scala:105-127):
+// the per-side statistic is the indexLagg-th / indexLead-th smallest cell of the window.
+// The hardware keeps each window sorted with a linear insertion sorter; here every thread keeps
+// ONE sorted window in registers: it bitonic-sorts the R cells starting at its first window
+// start, then slides it (branch-free delete + insert, cmp/cndmask + med3 per element) over its
+// run of consecutive starts, writing the two order statistics of every start to LDS.  The
+// lagging window of cell k starts at k - G - R, the leading one at k + G + 1, so a cell needs two
+// lookups.  Starts run over [-(G+R), N + G]; cells outside the frame come from the magnitude
+// halo (zeros or the wrapped image).
+
+template <typename V> __device__ __forceinline__ V vmin(V a, V b) { return a < b ? a : b; }
+template <typename V> __device__ __forceinline__ V vmax(V a, V b) { return a > b ? a : b; }
+template <> __device__ __forceinline__ float vmin<float>(float a, float b) { return fminf(a, b); }
+template <> __device__ __forceinline__ float vmax<float>(float a, float b) { return fmaxf(a, b); }
+// median of three, a <= c guaranteed by the caller
+template <typename V> __device__ __forceinline__ V vmed3(V a, V b, V c) { return vmin(vmax(a, b), c); }
+template <> __device__ __forceinline__ float vmed3<float>(float a, float b, float c) {
+  return __builtin_amdgcn_fmed3f(a, b, c);
+}
+
+template <typename V, int R>
+__device__ __forceinline__ void bitonic_sort(V (&s)[R]) {
+#pragma unroll
+  for (int k = 2; k <= R; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const int l = i ^ j;
+        if (l > i) {
+          const V lo = vmin(s[i], s[l]), hi = vmax(s[i], s[l]);
+          const bool asc = (i & k) == 0;
+          s[i] = asc ? lo : hi;
+          s[l] = asc ? hi : lo;
+        }
+      }
     }
   }
 }
 
+// sorted s: remove one element equal to `old`, insert `nw`, stay sorted
+template <typename V, int R>
+__device__ __forceinline__ void slide(V (&s)[R], V old, V nw) {
+  V t[R - 1];
+#pragma unroll
+  for (int i = 0; i < R - 1; ++i) t[i] = s[i] < old ? s[i] : s[i + 1];
+  s[0] = vmin(t[0], nw);
+#pragma unroll
+  for (int i = 1; i < R - 1; ++i) s[i] = vmed3(t[i - 1], nw, t[i]);
+  s[R - 1] = vmax(t[R - 2], nw);
+}
+
+// s[idx] for a wave-uniform idx: log2(R) levels of selects on the bits of idx
+template <typename V, int R>
+__device__ __forceinline__ V pick(const V (&s)[R], int idx) {
+  V a[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) a[i] = s[i];
+#pragma unroll
+  for (int w = R; w > 1; w >>= 1) {
+    const bool odd = (idx & 1) != 0;
+    idx >>= 1;
+#pragma unroll
+    for (int i = 0; i < w / 2; ++i) a[i] = odd ? a[2 * i + 1] : a[2 * i];
+  }
+  return a[0];
+}
+
+struct GosLayout {  // byte offsets inside a frame's LDS, computed on the host
+  int32_t frame_bytes, o1_off, o2_off, det_off, run;  // run = consecutive window starts per thread
+};
+
+template <typename V, int R>
+__device__ __forceinline__ void gos_stage(const V* mag, V* o1, V* o2, int tau, int run, int G,
+                                          int idx_lagg, int idx_lead) {
+  const int a0 = -(G + R) + run * tau;  // first window start of this thread
+  V s[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) s[i] = mag[pad(a0 + i + kHalo)];
+  bitonic_sort<V, R>(s);
+  const bool two = idx_lagg != idx_lead;
+  for (int st = 0; st < run; ++st) {
+    const int oi = pad(run * tau + st);
+    o1[oi] = pick<V, R>(s, idx_lagg);
+    if (two) o2[oi] = pick<V, R>(s, idx_lead);
+    if (st + 1 < run) {
+      const V old = mag[pad(a0 + st + kHalo)], nw = mag[pad(a0 + st + R + kHalo)];
+      slide<V, R>(s, old, nw);
+    }
+  }
+}
+
+template <int M, bool FIXED>
+__global__ void __launch_bounds__(wg_size(M))
+chain1d_gos_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t n_frames,
+                   ChainRegs rg, GosLayout lay, const void* __restrict__ tw,
+                   const int16_t* __restrict__ log_lut, uint32_t* __restrict__ fcount,
+                   uint2* __restrict__ fdet, uint32_t* __restrict__ zero_a,
+                   uint32_t* __restrict__ zero_b) {
+  constexpr int N = 1 << M, T = threads_per_frame(M), FPW = frames_per_wg(M);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (zero_a) *zero_a = 0u;
+    if (zero_b) *zero_b = 0u;
+  }
+  using V = typename std::conditional<FIXED, int, float>::type;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int fl = tid / T, tau = tid % T;
+  const uint32_t frame = blockIdx.x * FPW + fl;
+  const bool live = frame < n_frames;
+  unsigned char* fbase = smem + (size_t)fl * lay.frame_bytes;
+
+  V mg[16];
+  front_end<M, FIXED, V>(in, frame, live, tau, fbase, rg, tw, log_lut, mg);
+
+  V* mag = reinterpret_cast<V*>(fbase);  // cell x in [-256, N + 256] at slot pad(x + 256)
+  V* o1 = reinterpret_cast<V*>(fbase + lay.o1_off);
+  V* o2 = reinterpret_cast<V*>(fbase + lay.o2_off);
+  uint32_t* det_cnt = reinterpret_cast<uint32_t*>(fbase + lay.det_off);
+  uint2* det_stage = reinterpret_cast<uint2*>(fbase + lay.det_off + 8);
+  const bool wrap = rg.edge != 0;
+  __syncthreads();  // every thread is done reading the FFT image this overlays
+  write_mag<M, V>(mag, kHalo, tau, mg);
+  if (tau == 0) *det_cnt = 0u;
+  __syncthreads();
+  for (int h = tau; h < 32; h += T) {  // halos: 32 runs of 16 cells, zeros or the wrapped image
+    const int x0 = h < 16 ? -kHalo + 16 * h : N + 16 * (h - 16);
+    const int src = h < 16 ? x0 + N : x0 - N;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mag[pad(x0 + e + kHalo)] = wrap ? mag[pad(src + e + kHalo)] : V(0);
+    if (h == 31) mag[pad(N + kHalo + kHalo)] = wrap ? mag[pad(kHalo + kHalo)] : V(0);
+  }
+  __syncthreads();
+  switch (rg.R) {
+    case 4: gos_stage<V, 4>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead); break;
+    case 8: gos_stage<V, 8>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead); break;
+    case 16: gos_stage<V, 16>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead); break;
+    case 32: gos_stage<V, 32>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead); break;
+    default: gos_stage<V, 64>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead); break;
+  }
+  __syncthreads();
+
+  // cell k = tau + T j: lagging statistic = o1[k] (window start k - G - R), leading = o2[k + 2G + R + 1]
+  uint32_t word[16];
+  {
+    constexpr int JS = T + T / 16;
+    const V* pl = o1 + pad(tau);
+    const V* pr = o2 + pad(tau + 2 * rg.G + rg.R + 1);
+    const V* pm = mag + pad(tau + kHalo);
+    const int dl = ((tau & 15) == 0) ? 2 : 1, dr = ((tau & 15) == 15) ? 2 : 1;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const V a = pl[JS * j], b = pr[JS * j];
+      V stat;
+      if (rg.cfar_mode == 0) stat = CfarMath<V>::half_sum(a, b);
+      else if (rg.cfar_mode == 1) stat = a > b ? a : b;
+      else stat = a < b ? a : b;
+      const V cut = pm[JS * j];
+      bool group_ok = true;
+      if (rg.peak_grouping) group_ok = cut > pm[JS * j - dl] && cut > pm[JS * j + dr];
+      word[j] = CfarMath<V>::finish(stat, cut, group_ok, tau + T * j, M, rg);
+    }
+  }
+  emit_words<M>(word, out, frame, live, tau, det_cnt, det_stage, fcount, fdet);
+}
+
 // ---------------------------------------------------------------- launcher
+
+// GOS kernel LDS: magnitude with 256-cell halos + one or two order-statistic arrays + staging
+template <int M>
+static GosLayout gos_layout(const ChainRegs& rg) {
+  constexpr int N = 1 << M, T = threads_per_frame(M);
+  GosLayout l;
+  l.run = (N + 2 * rg.G + rg.R + 1 + T - 1) / T;
+  const int mag_bytes = 4 * (pad_slots(N + 2 * kHalo) + 2);
+  const int o_bytes = 4 * (pad_slots(l.run * T) + 2);
+  l.o1_off = mag_bytes;
+  l.o2_off = rg.idx_lagg != rg.idx_lead ? l.o1_off + o_bytes : l.o1_off;
+  l.det_off = (l.o2_off + o_bytes + 7) & ~7;
+  const int total = l.det_off + 8 + 8 * kFrameDetCap;
+  l.frame_bytes = ((total > FrameLds<M>::FFT_BYTES ? total : FrameLds<M>::FFT_BYTES) + 15) & ~15;
+  return l;
+}
+
+template <int M>
+static hipError_t launch_gos(const Chain1dLaunch& a) {
+  const uint32_t fpw = frames_per_wg(M);
+  const uint32_t grid = (a.n_frames + fpw - 1) / fpw;
+  const GosLayout lay = gos_layout<M>(a.regs);
+  const size_t lds = (size_t)lay.frame_bytes * fpw;
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  hipError_t e;
+  if (a.fixed) {
+    auto k = chain1d_gos_kernel<M, true>;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(wg_size(M)), lds, a.stream, a.in, a.out, a.n_frames, a.regs, lay,
+                       a.twiddles, a.log_lut, a.frame_count, a.frame_det, a.zero_a, a.zero_b);
+  } else {
+    auto k = chain1d_gos_kernel<M, false>;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(wg_size(M)), lds, a.stream, a.in, a.out, a.n_frames, a.regs, lay,
+                       a.twiddles, a.log_lut, a.frame_count, a.frame_det, a.zero_a, a.zero_b);
+  }
+  return hipGetLastError();
+}
 
 template <int M>
 static hipError_t launch_m(const Chain1dLaunch& a) {
+  if (a.regs.algorithm == 1) return launch_gos<M>(a);
   const uint32_t fpw = frames_per_wg(M);
   const uint32_t grid = (a.n_frames + fpw - 1) / fpw;
   size_t lds = FrameLds<M>::BYTES * fpw;

@@ -213,7 +213,11 @@ int check_regs(const rsp_chain* c) {
       return fail(RSP_ERR_INVALID, "indexLagg/indexLead = %u/%u must be < refWindowSize = %d", c->cfar[kIndexLagg], c->cfar[kIndexLead], R);
   }
   if (c->cfar[kAlgorithm] > 1) return fail(RSP_ERR_INVALID, "cfarAlgorithm register = %u", c->cfar[kAlgorithm]);
-  if (uses_gos(c)) return fail(RSP_ERR_UNSUPPORTED, "GOS (ordered-statistic) CFAR is not available in this build");
+  if (uses_gos(c)) {
+    if (R < 4 || R > 64) return fail(RSP_ERR_UNSUPPORTED, "GOS CFAR: refWindowSize = %d, the GPU sorter is built for 4..64", R);
+    if (m == rsp::kMaxLog2N && c->cfar[kIndexLagg] != c->cfar[kIndexLead])
+      return fail(RSP_ERR_UNSUPPORTED, "GOS CFAR at %d points needs indexLagg == indexLead (LDS)", n);
+  }
   if (c->cfar[kScaler] > 0xFFFFu) return fail(RSP_ERR_INVALID, "thresholdScaler register = 0x%x exceeds protoScaler's 16 bits", c->cfar[kScaler]);
   return RSP_OK;
 }

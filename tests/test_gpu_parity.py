@@ -231,3 +231,43 @@ def test_cpp_host_tester_replays_dumps(gpu, tmp_path):
     params, rt = make_params(n), R.RunTimeRspChainParams()
     ref = O.chain_fixed(R.stimulus.formAXI4StreamComplexData(z), oracle_cfg(params, rt))
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("n,ref,guard,idx", [(256, 4, 1, (1, 2)), (1024, 16, 2, (11, 11)), (1024, 32, 4, (24, 8)),
+                                            (4096, 64, 4, (48, 48)), (8192, 32, 4, (24, 24))])
+@pytest.mark.parametrize("mode", ["Cell Averaging", "Greatest Of", "Smallest Of"])
+def test_fixed_gos_bit_exact(gpu, n, ref, guard, idx, mode):
+    """GOSCFARType (FftMagCfarChainTester.scala:105,123-127): ordered-statistic CFAR, bit-exact."""
+    params = make_params(n, alg=R.GOSCFARType, edge="wrap" if ref == 16 else "zero")
+    rt = R.RunTimeRspChainParams(fftSize=n, CFARMode=mode, refWindowSize=ref, guardWindowSize=guard, divSum=None,
+                                 indexLagg=idx[0], indexLead=idx[1], thresholdScaler=1.5, peakGrouping=1 if ref == 4 else 0)
+    beats = np.concatenate([tone_beats(2, n, 60 + n), random_beats(3, n, n + 1)])
+    got = run_fixed(params, rt, beats)
+    ref_out = O.chain_fixed(beats, oracle_cfg(params, rt)).reshape(got.shape)
+    assert np.array_equal(got, ref_out)
+
+
+def test_gosca_runtime_algorithm_select(gpu):
+    """GOSCACFARType: register 0x14 picks CA or GOS at run time (Tester:110-118)."""
+    n = 1024
+    params = make_params(n, alg=R.GOSCACFARType)
+    beats = np.concatenate([tone_beats(2, n, 5), random_beats(2, n, 6)])
+    for alg in ("CA", "GOS"):
+        rt = R.RunTimeRspChainParams(CFARAlgorithm=alg, indexLagg=20, indexLead=20)
+        got = run_fixed(params, rt, beats)
+        assert np.array_equal(got, O.chain_fixed(beats, oracle_cfg(params, rt)).reshape(got.shape)), alg
+
+
+@pytest.mark.parametrize("n,ref,idx", [(8192, 32, 24), (2048, 16, 12)])
+def test_f32_gos(gpu, n, ref, idx):
+    """BASELINE.json configs[3]: OS-CFAR, 32-cell window, 8192-point spectrum (k = 3R/4, G = 4)."""
+    params = make_params(n, dtype=R.F32, alg=R.GOSCFARType)
+    rt = R.RunTimeRspChainParams(fftSize=n, CFARMode="Greatest Of", refWindowSize=ref, guardWindowSize=4, divSum=None,
+                                 indexLagg=idx, indexLead=idx, thresholdScaler=2.5)
+    x = R.stimulus.chirp_frames(3, n, seed=3456)
+    with R.FftMagCfarChainVanilla(params) as dut:
+        dut.configure(rt)
+        words = dut.stream(x)
+    thr, peak, margin, mag = O.chain_f32(x, oracle_fcfg(params, rt), want_mag=True)
+    compare_f32(words, thr, peak, margin, mag)
+    assert np.all((words & 1).sum(axis=1) >= 3)
