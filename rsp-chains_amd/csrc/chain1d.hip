@@ -565,20 +565,23 @@ __device__ __forceinline__ void slide(V (&s)[R], V old, V nw) {
   s[R - 1] = vmax(t[R - 2], nw);
 }
 
-// s[idx] for a wave-uniform idx: log2(R) levels of selects on the bits of idx
+// s[idx] for a wave-uniform idx: log2(R) levels of bitwise blends (v_bfi_b32) on the bits of idx.
+// Written on the bit patterns on purpose: a `cond ? a[2i+1] : a[2i]` with a uniform cond is
+// turned by the compiler into an indexed load from a scratch copy of the array (10x slower).
 template <typename V, int R>
 __device__ __forceinline__ V pick(const V (&s)[R], int idx) {
-  V a[R];
+  uint32_t a[R];
 #pragma unroll
-  for (int i = 0; i < R; ++i) a[i] = s[i];
+  for (int i = 0; i < R; ++i) a[i] = __builtin_bit_cast(uint32_t, s[i]);
 #pragma unroll
   for (int w = R; w > 1; w >>= 1) {
-    const bool odd = (idx & 1) != 0;
+    uint32_t m = (idx & 1) ? 0xffffffffu : 0u;
+    asm volatile("" : "+s"(m));  // keep it a value, not a branch / address select
     idx >>= 1;
 #pragma unroll
-    for (int i = 0; i < w / 2; ++i) a[i] = odd ? a[2 * i + 1] : a[2 * i];
+    for (int i = 0; i < w / 2; ++i) a[i] = (a[2 * i + 1] & m) | (a[2 * i] & ~m);
   }
-  return a[0];
+  return __builtin_bit_cast(V, a[0]);
 }
 
 struct GosLayout {  // byte offsets inside a frame's LDS, computed on the host

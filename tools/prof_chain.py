@@ -13,9 +13,11 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 dtype = R.F32 if (len(sys.argv) <= 4 or sys.argv[4] == "f32") else R.FIXED16
+gos = len(sys.argv) > 5 and sys.argv[5] == "gos"
 params = R.FftMagCfarVanillaParameters(fftParams=R.FFTParams.fixed(numPoints=n), magParams=R.MAGParams.fixed(),
-                                       cfarParams=R.CFARParams(fftSize=n), dtype=dtype)
-rt = R.RunTimeRspChainParams(fftSize=n, CFARMode="Cell Averaging", refWindowSize=32, guardWindowSize=4, divSum=5)
+                                       cfarParams=R.CFARParams(fftSize=n, CFARAlgorithm=R.GOSCFARType if gos else R.CACFARType), dtype=dtype)
+rt = (R.RunTimeRspChainParams(fftSize=n, CFARMode="Greatest Of", refWindowSize=32, guardWindowSize=4, divSum=None, indexLagg=24, indexLead=24)
+      if gos else R.RunTimeRspChainParams(fftSize=n, CFARMode="Cell Averaging", refWindowSize=32, guardWindowSize=4, divSum=5))
 dut = R.FftMagCfarChainVanilla(params)
 dut.configure(rt)
 sets = 4
@@ -36,4 +38,6 @@ dut.timer_start()
 for i in range(reps):
     dut.process_device(ins[i % sets].ptr, frames, outs[i % sets].ptr)
 ms = dut.timer_stop() / reps
-print(f"chain1d n={n} frames={frames} {ms*1e3:.1f} us/launch")
+cells = n * frames
+bpc = (12 if dtype == R.F32 else 8)
+print(f"chain1d n={n} frames={frames} {'gos' if gos else 'ca'} {'f32' if dtype == R.F32 else 'fx16'} {ms*1e3:.1f} us/launch  {cells/ms/1e6:.1f} Gcells/s  {cells*bpc/ms/1e9:.2f} TB/s algorithmic")
