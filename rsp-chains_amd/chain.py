@@ -151,6 +151,11 @@ class FftMagCfarVanillaParameters:
     beatBytes: int = 4
     dtype: int = FIXED16
     device: int = 0
+    # 2-D range-Doppler chain (BASELINE.json configs 3/5; no reference counterpart): slow-time FFT
+    # size (0 = the reference's 1-D chain) and the Doppler half-widths of the 2-D CA-CFAR
+    dopplerPoints: int = 0
+    refDoppler: int = 0
+    guardDoppler: int = 0
 
     def to_c(self) -> N.ChainParamsC:
         p = N.ChainParamsC()
@@ -186,6 +191,7 @@ class FftMagCfarVanillaParameters:
             a = getattr(self, name)
             getattr(p, name).base, getattr(p, name).mask = a.base, a.mask
         p.beatBytes, p.dtype, p.device = self.beatBytes, self.dtype, self.device
+        p.dopplerPoints, p.refDoppler, p.guardDoppler = self.dopplerPoints, self.refDoppler, self.guardDoppler
         return p
 
 
@@ -305,6 +311,11 @@ class FftMagCfarChainVanilla:
     def fftSize(self) -> int:
         return 1 << self.memReadWord(self.params.fftAddress.base)
 
+    @property
+    def frameCells(self) -> int:
+        """beats per frame: fftSize (1-D chain) or dopplerPoints x fftSize (one channel's 2-D map)"""
+        return self.fftSize * (self.params.dopplerPoints or 1)
+
     def _as_beats(self, beats) -> np.ndarray:
         if self.params.dtype == FIXED16:
             a = np.ascontiguousarray(beats, dtype=np.uint32).ravel()
@@ -312,7 +323,7 @@ class FftMagCfarChainVanilla:
         else:
             a = np.ascontiguousarray(beats, dtype=np.complex64).ravel()
             cells = a.size
-        n = self.fftSize
+        n = self.frameCells
         if cells % n:
             raise ValueError(f"requirement failed: {cells} beats is not a whole number of {n}-beat frames "
                              "(TLAST closes every frame)")
@@ -322,10 +333,12 @@ class FftMagCfarChainVanilla:
         """Enqueue whole frames (TLAST on each frame's final beat, Tester:137) and
         collect fftSize output words per frame (Tester:145-151)."""
         a = self._as_beats(beats)
-        n = self.fftSize
+        n = self.frameCells
         out = np.empty(a.size, np.uint32)
         _check(self._lib.rsp_chain_process(self._h, a.ctypes.data_as(C.c_void_p), a.size // n,
                                            out.ctypes.data_as(C.c_void_p)))
+        if self.params.dopplerPoints:
+            return out.reshape(-1, self.params.dopplerPoints, self.fftSize)
         return out.reshape(-1, n)
 
     def detections(self, beats, cap: int = 1 << 20):

@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "chain_regs.hpp"
 
 namespace rsp {
@@ -163,6 +165,57 @@ __device__ __forceinline__ void pass_f32(f32x2 (&x)[16], int tau, const f32x2* _
       }
     }
   }
+}
+
+// Whole F32 FFT of one frame through the LDS image `buf`.  load(d) returns the sample at the
+// thread's first sample index + d (d is a compile-time constant after unrolling, so the caller's
+// address arithmetic folds into immediates).  On return x[g 2^WL + p] holds, unscaled, bin
+// (bitrev(p) << (M - WL)) | bitrev_{M-WL}(g T + tau), WL = width of the last pass.
+template <int M, typename Load>
+__device__ __forceinline__ void fft_f32_frame(Load load, int tau, f32x2* buf,
+                                              const f32x2* __restrict__ tw, f32x2 (&x)[16]) {
+  constexpr int NP = plan_np(M);
+  {
+    constexpr int W = plan_w(M, 0), LO = plan_lo(M, 0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x[e] = load(elem_index<M, LO, W>(0, e) - elem_index<M, LO, W>(0, 0));
+  }
+  pass_f32<M, 0>(x, tau, tw);
+  auto exchange = [&](auto pc) {
+    constexpr int P = decltype(pc)::value;
+    constexpr int W0 = plan_w(M, P - 1), LO0 = plan_lo(M, P - 1);
+    constexpr int W1 = plan_w(M, P), LO1 = plan_lo(M, P);
+#pragma unroll
+    for (int g = 0; g < (16 >> W0); ++g) {
+      f32x2* b0 = buf + slot_base<M, LO0, W0>(tau, g);
+#pragma unroll
+      for (int r = 0; r < (1 << W0); ++r) b0[slot_delta<LO0, W0>(r)] = x[g * (1 << W0) + r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < (16 >> W1); ++g) {
+      const f32x2* b1 = buf + slot_base<M, LO1, W1>(tau, g);
+#pragma unroll
+      for (int r = 0; r < (1 << W1); ++r) x[g * (1 << W1) + r] = b1[slot_delta<LO1, W1>(r)];
+    }
+    pass_f32<M, P>(x, tau, tw);
+  };
+  exchange(std::integral_constant<int, 1>{});
+  if constexpr (NP > 2) exchange(std::integral_constant<int, 2>{});
+  if constexpr (NP > 3) exchange(std::integral_constant<int, 3>{});
+}
+
+// first sample index of thread tau in pass 0 (its other 15 are at compile-time offsets from it)
+template <int M>
+__device__ __forceinline__ int first_sample(int tau) {
+  return elem_index<M, plan_lo(M, 0), plan_w(M, 0)>(tau, 0);
+}
+
+// bin held in register (g, p) after fft_f32_frame
+template <int M>
+__device__ __forceinline__ int bin_of(int tau, int g, int p) {
+  constexpr int NP = plan_np(M), WL = plan_w(M, NP - 1), T = threads_per_frame(M);
+  return (bitrev_c(p, WL) << (M - WL)) | (int)(__brev((unsigned)(g * T + tau)) >> (32 - (M - WL)));
 }
 
 // ---------------------------------------------------------------- FIXED16 pieces

@@ -30,6 +30,22 @@ struct Chain1dLaunch {
 hipError_t launch_chain1d(const Chain1dLaunch& a);
 size_t chain1d_lds_bytes(int log2n);
 
+// 2-D range-Doppler chain (rd2d.hip): in [n_ch][nd][nr] complex64 -> out [n_ch][nd][nr] words
+struct Rd2dLaunch {
+  const void* in;
+  uint32_t* out;
+  uint32_t n_ch;
+  int log2nr, log2nd;
+  ChainRegs regs;       // mag_mode, scaler, linear, edge; R / G = range training / guard half-widths
+  int ref_d, guard_d;   // Doppler training / guard half-widths
+  const void* tw_range;
+  const void* tw_doppler;
+  void* scratch_complex;  // device: n_ch * nd * nr * 8 B
+  float* scratch_mag;     // device: n_ch * nd * nr * 4 B
+  hipStream_t stream;
+};
+hipError_t launch_rd2d(const Rd2dLaunch& a);
+
 hipError_t launch_compact_frames(const uint32_t* fcount, const uint2* fdet, uint32_t n_frames,
                                  rsp_detection* list, uint32_t cap, uint32_t* counters,
                                  uint32_t* d_count, hipStream_t stream);

@@ -1,0 +1,233 @@
+// 2-D range-Doppler chain: range FFT -> Doppler FFT -> magnitude -> 2-D CA-CFAR.
+//
+// No reference counterpart: every chain under /root/reference/src/main/scala holds ONE 1-D FFT
+// (SURVEY F5); this is BASELINE.json configs[2] / configs[4], specified by
+// oracle/rsp_oracle.c::orc_rd_f32in.  A channel's map is [doppler d][range r], row-major.
+//
+//   range_fft_kernel   rows: FFT over r (contiguous), complex out in natural order  (8 R + 8 W)
+//   doppler_mag_kernel columns: FFT over d for 16 adjacent range bins per workgroup so that
+//                      every global access is a 128-B (in) / 64-B (out) segment; |.| out (8 R + 4 W)
+//   cfar2d_kernel      tile + halo in LDS, separable sliding box sums (outer - guard box),
+//                      threshold, word out                                           (4 R + 4 W)
+// = 36 B/cell against the 28 B/cell a fully fused Doppler+CFAR pass would need (the CFAR halo
+// crosses workgroup tiles in range; fusing it means recomputing halo columns' FFTs).
+#include <hip/hip_runtime.h>
+#include <float.h>
+
+#include "chain_regs.hpp"
+#include "fft_lds.hpp"
+#include "kernels.hpp"
+
+namespace rsp {
+
+__device__ __forceinline__ float mag2d(f32x2 z, int mode) {
+  const float ar = fabsf(z.x), ai = fabsf(z.y);
+  const float u = fmaxf(ar, ai), v = fminf(ar, ai);
+  const float jpl = fmaxf(u + v * 0.125f, u * 0.875f + v * 0.5f);  // RspChainTesterUtils.scala:120-127
+  if (mode == 2) return jpl;
+  if (mode == 0) return z.x * z.x + z.y * z.y;
+  return __log2f(fmaxf(jpl, FLT_MIN));
+}
+
+// ---------------------------------------------------------------- range pass (rows)
+template <int M>
+__global__ void __launch_bounds__(wg_size(M))
+range_fft_kernel(const f32x2* __restrict__ in, f32x2* __restrict__ out, uint32_t n_rows,
+                 const f32x2* __restrict__ tw) {
+  constexpr int N = 1 << M, T = threads_per_frame(M), FPW = frames_per_wg(M);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, fl = tid / T, tau = tid % T;
+  const uint32_t row = blockIdx.x * FPW + fl;
+  const bool live = row < n_rows;
+  f32x2* buf = reinterpret_cast<f32x2*>(smem) + (size_t)fl * pad_slots(N);
+  const f32x2* src = in + (size_t)(live ? row : 0) * N + first_sample<M>(tau);
+  f32x2 x[16];
+  fft_f32_frame<M>([&](int d) { return src[d]; }, tau, buf, tw, x);
+  // natural order through LDS, then 512 B per wave-instruction to HBM
+  constexpr int NP = plan_np(M), WL = plan_w(M, NP - 1);
+  const float scale = 1.0f / (float)N;
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < (16 >> WL); ++g) {
+#pragma unroll
+    for (int p = 0; p < (1 << WL); ++p) buf[pad(bin_of<M>(tau, g, p))] = x[g * (1 << WL) + p] * scale;
+  }
+  __syncthreads();
+  if (!live) return;
+  f32x2* dst = out + (size_t)row * N;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) dst[tau + T * j] = buf[pad(tau + T * j)];
+}
+
+// ---------------------------------------------------------------- Doppler pass (columns) + magnitude
+constexpr int kColsPerWg(int MD) { return MD >= 10 ? 8 : 16; }
+// LDS bytes per column: the padded FFT image + 32 B so that adjacent columns start 8 banks apart
+constexpr int kColBytes(int MD) { return 8 * pad_slots(1 << MD) + 32; }
+
+template <int MD>
+__global__ void __launch_bounds__(threads_per_frame(MD) * kColsPerWg(MD))
+doppler_mag_kernel(const f32x2* __restrict__ in, float* __restrict__ mag, uint32_t n_ch, uint32_t nr,
+                   int mag_mode, const f32x2* __restrict__ tw) {
+  constexpr int ND = 1 << MD, T = threads_per_frame(MD), C = kColsPerWg(MD);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // lanes run over the C adjacent range bins first: a wave touches 64 / C rows x (C x 8 B) segments
+  const int tid = threadIdx.x, fl = tid % C, tau = tid / C;
+  const uint32_t tiles_per_ch = nr / C;
+  const uint32_t ch = blockIdx.x / tiles_per_ch, r0 = (blockIdx.x % tiles_per_ch) * C;
+  f32x2* buf = reinterpret_cast<f32x2*>(smem + (size_t)fl * kColBytes(MD));
+  const size_t col = (size_t)ch * ND * nr + r0 + fl;  // element index of (ch, d = 0, r)
+  const f32x2* src = in + col + (size_t)first_sample<MD>(tau) * nr;
+  f32x2 x[16];
+  fft_f32_frame<MD>([&](int d) { return src[(size_t)d * nr]; }, tau, buf, tw, x);
+  constexpr int NP = plan_np(MD), WL = plan_w(MD, NP - 1);
+  const float scale = 1.0f / (float)ND;
+  float* dst = mag + col;
+#pragma unroll
+  for (int g = 0; g < (16 >> WL); ++g) {
+#pragma unroll
+    for (int p = 0; p < (1 << WL); ++p)
+      dst[(size_t)bin_of<MD>(tau, g, p) * nr] = mag2d(x[g * (1 << WL) + p] * scale, mag_mode);
+  }
+}
+
+// ---------------------------------------------------------------- 2-D CA-CFAR
+// Training region = (2(ref_r+guard_r)+1) x (2(ref_d+guard_d)+1) box minus the guard box; out-of-map
+// range cells read zero (edge 0) or wrap (edge 1), Doppler is cyclic; statistic = sum / count.
+constexpr int kTD = 32, kTR = 64;  // output tile: 32 Doppler rows x 64 range bins per workgroup
+
+__global__ void __launch_bounds__(256)
+cfar2d_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_t nd, uint32_t nr,
+              int ref_r, int guard_r, int ref_d, int guard_d, int edge, float kA, float kB) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int hr = ref_r + guard_r, hd = ref_d + guard_d;
+  const int RW = kTR + 2 * hr, RH = kTD + 2 * hd;  // haloed region
+  const int MS = RW + 1;                            // row pitch of the magnitude region
+  float* m = reinterpret_cast<float*>(smem);        // [RH][MS]
+  float* ro = m + RH * MS;                          // outer row sums [RH][kTR + 1]
+  float* ri = ro + RH * (kTR + 1);                  // guard row sums [RH][kTR + 1]
+  const int tid = threadIdx.x;
+  const uint32_t tiles_r = nr / kTR, tiles_d = nd / kTD;
+  const uint32_t ch = blockIdx.x / (tiles_r * tiles_d);
+  const uint32_t t = blockIdx.x % (tiles_r * tiles_d);
+  const int d0 = (int)(t / tiles_r) * kTD, r0 = (int)(t % tiles_r) * kTR;
+  const float* map = mag + (size_t)ch * nd * nr;
+
+  // 1. region -> LDS (coalesced along r)
+  for (int i = tid; i < RH * RW; i += 256) {
+    const int rr = i % RW, dd = i / RW;
+    int r = r0 - hr + rr;
+    const int d = (d0 - hd + dd + (int)nd) & ((int)nd - 1);  // Doppler cyclic (nd is a power of two)
+    float v = 0.f;
+    if (edge) r = (r + (int)nr) & ((int)nr - 1);
+    if (r >= 0 && r < (int)nr) v = map[(size_t)d * nr + r];
+    m[dd * MS + rr] = v;
+  }
+  __syncthreads();
+  // 2. row pass: sliding sums along r, one task = (region row, run of 16 output columns)
+  for (int task = tid; task < RH * (kTR / 16); task += 256) {
+    const int dd = task / (kTR / 16), c0 = (task % (kTR / 16)) * 16;
+    const float* row = m + dd * MS + c0 + hr;  // row[c] = cell at output column c0 + c
+    float so = 0.f, si = 0.f;
+    for (int k = -hr; k <= hr; ++k) so += row[k];
+    for (int k = -guard_r; k <= guard_r; ++k) si += row[k];
+    float* po = ro + dd * (kTR + 1) + c0;
+    float* pi = ri + dd * (kTR + 1) + c0;
+    for (int c = 0; c < 16; ++c) {
+      po[c] = so;
+      pi[c] = si;
+      so += row[c + hr + 1] - row[c - hr];
+      si += row[c + guard_r + 1] - row[c - guard_r];
+    }
+  }
+  __syncthreads();
+  // 3. column pass: thread = (output column, run of 8 output rows); stores are 256 B per wave
+  {
+    const int c = tid & (kTR - 1), dseg = (tid / kTR) * (kTD / 4);
+    const float count = (float)((2 * hr + 1) * (2 * hd + 1) - (2 * guard_r + 1) * (2 * guard_d + 1));
+    const float kAc = kA / count;
+    const float* co = ro + (dseg + hd) * (kTR + 1) + c;  // co[k (kTR+1)] = outer row sum at output row dseg + k
+    const float* ci = ri + (dseg + hd) * (kTR + 1) + c;
+    float so = 0.f, si = 0.f;
+    for (int k = -hd; k <= hd; ++k) so += co[k * (kTR + 1)];
+    for (int k = -guard_d; k <= guard_d; ++k) si += ci[k * (kTR + 1)];
+    uint32_t* dst = out + ((size_t)ch * nd + d0 + dseg) * nr + r0 + c;
+    for (int j = 0; j < kTD / 4; ++j) {
+      const float thr = __fmaf_rn(so - si, kAc, kB);
+      const float cut = m[(dseg + j + hd) * MS + c + hr];
+      dst[(size_t)j * nr] = (__float_as_uint(thr) & ~1u) | (uint32_t)(cut > thr);
+      so += co[(j + hd + 1) * (kTR + 1)] - co[(j - hd) * (kTR + 1)];
+      si += ci[(j + guard_d + 1) * (kTR + 1)] - ci[(j - guard_d) * (kTR + 1)];
+    }
+  }
+}
+
+// ---------------------------------------------------------------- launchers
+
+template <int M>
+static hipError_t launch_range_m(const f32x2* in, f32x2* out, uint32_t n_rows, const f32x2* tw,
+                                 hipStream_t s) {
+  const uint32_t fpw = frames_per_wg(M);
+  const size_t lds = (size_t)8 * pad_slots(1 << M) * fpw;
+  auto k = range_fft_kernel<M>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(k, dim3((n_rows + fpw - 1) / fpw), dim3(wg_size(M)), lds, s, in, out, n_rows, tw);
+  return hipGetLastError();
+}
+
+template <int MD>
+static hipError_t launch_doppler_m(const f32x2* in, float* mag, uint32_t n_ch, uint32_t nr, int mode,
+                                   const f32x2* tw, hipStream_t s) {
+  constexpr int C = kColsPerWg(MD);
+  const size_t lds = (size_t)kColBytes(MD) * C;
+  auto k = doppler_mag_kernel<MD>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k, dim3(n_ch * (nr / C)), dim3(threads_per_frame(MD) * C), lds, s, in, mag, n_ch,
+                     nr, mode, tw);
+  return hipGetLastError();
+}
+
+hipError_t launch_rd2d(const Rd2dLaunch& a) {
+  if (a.n_ch == 0) return hipSuccess;
+  const uint32_t nr = 1u << a.log2nr, nd = 1u << a.log2nd;
+  hipError_t e;
+  const f32x2* in = reinterpret_cast<const f32x2*>(a.in);
+  f32x2* x1 = reinterpret_cast<f32x2*>(a.scratch_complex);
+  const f32x2* twr = reinterpret_cast<const f32x2*>(a.tw_range);
+  const f32x2* twd = reinterpret_cast<const f32x2*>(a.tw_doppler);
+  const uint32_t rows = a.n_ch * nd;
+  switch (a.log2nr) {
+    case 8: e = launch_range_m<8>(in, x1, rows, twr, a.stream); break;
+    case 9: e = launch_range_m<9>(in, x1, rows, twr, a.stream); break;
+    case 10: e = launch_range_m<10>(in, x1, rows, twr, a.stream); break;
+    case 11: e = launch_range_m<11>(in, x1, rows, twr, a.stream); break;
+    case 12: e = launch_range_m<12>(in, x1, rows, twr, a.stream); break;
+    case 13: e = launch_range_m<13>(in, x1, rows, twr, a.stream); break;
+    default: return hipErrorInvalidValue;
+  }
+  if (e != hipSuccess) return e;
+  switch (a.log2nd) {
+    case 8: e = launch_doppler_m<8>(x1, a.scratch_mag, a.n_ch, nr, a.regs.mag_mode, twd, a.stream); break;
+    case 9: e = launch_doppler_m<9>(x1, a.scratch_mag, a.n_ch, nr, a.regs.mag_mode, twd, a.stream); break;
+    case 10: e = launch_doppler_m<10>(x1, a.scratch_mag, a.n_ch, nr, a.regs.mag_mode, twd, a.stream); break;
+    default: return hipErrorInvalidValue;
+  }
+  if (e != hipSuccess) return e;
+  const int hr = a.regs.R + a.regs.G, hd = a.ref_d + a.guard_d;
+  const size_t lds = 4 * ((size_t)(kTD + 2 * hd) * (kTR + 2 * hr + 1) + 2 * (size_t)(kTD + 2 * hd) * (kTR + 1));
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(cfar2d_kernel),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  const float kA = a.regs.linear ? a.regs.scaler_f : 1.0f, kB = a.regs.linear ? 0.0f : a.regs.scaler_f;
+  hipLaunchKernelGGL(cfar2d_kernel, dim3(a.n_ch * (nr / kTR) * (nd / kTD)), dim3(256), lds, a.stream,
+                     a.scratch_mag, a.out, nd, nr, a.regs.R, a.regs.G, a.ref_d, a.guard_d, a.regs.edge, kA, kB);
+  return hipGetLastError();
+}
+
+}  // namespace rsp

@@ -78,6 +78,10 @@ struct rsp_chain {
   uint32_t* d_fcount = nullptr;  // per-frame peak counts of the fused path
   uint2* d_fdet = nullptr;       // per-frame peak slots
   size_t fslots = 0;             // frames the two buffers above hold
+  void* d_x1 = nullptr;          // 2-D chain: range-pass spectrum
+  size_t d_x1_bytes = 0;
+  float* d_mag2 = nullptr;       // 2-D chain: magnitude map
+  size_t d_mag2_bytes = 0;
   // per-launch HIP-event timing of the chain kernel alone (rsp_chain_profile_*)
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -151,7 +155,13 @@ int validate(const rsp_chain_params* p) {
     }
   }
   if (p->cfarAddress.mask < 4 * kNumCfarRegs - 1) return fail(RSP_ERR_INVALID, "cfarAddress mask 0x%x too small for 12 registers", p->cfarAddress.mask);
-  if (p->dopplerPoints != 0) return fail(RSP_ERR_UNSUPPORTED, "dopplerPoints = %d: 2-D chain not available in this build", p->dopplerPoints);
+  if (p->dopplerPoints != 0) {  // 2-D range-Doppler chain (no reference counterpart; BASELINE.json configs 3/5)
+    if (p->dtype != RSP_DTYPE_F32) return fail(RSP_ERR_UNSUPPORTED, "the 2-D chain is implemented for RSP_DTYPE_F32 only");
+    if (!is_pow2(p->dopplerPoints) || p->dopplerPoints < 256 || p->dopplerPoints > 1024)
+      return fail(RSP_ERR_UNSUPPORTED, "dopplerPoints = %d: 256, 512 or 1024", p->dopplerPoints);
+    if (p->refDoppler < 1 || p->guardDoppler < 0 || p->refDoppler + p->guardDoppler > 32)
+      return fail(RSP_ERR_INVALID, "refDoppler/guardDoppler = %d/%d", p->refDoppler, p->guardDoppler);
+  }
   return RSP_OK;
 }
 
@@ -217,6 +227,12 @@ int check_regs(const rsp_chain* c) {
     if (R < 4 || R > 64) return fail(RSP_ERR_UNSUPPORTED, "GOS CFAR: refWindowSize = %d, the GPU sorter is built for 4..64", R);
     if (m == rsp::kMaxLog2N && c->cfar[kIndexLagg] != c->cfar[kIndexLead])
       return fail(RSP_ERR_UNSUPPORTED, "GOS CFAR at %d points needs indexLagg == indexLead (LDS)", n);
+  }
+  if (p.dopplerPoints) {
+    if (m != m_max) return fail(RSP_ERR_UNSUPPORTED, "2-D chain: run-time FFT size must equal numPoints");
+    if (c->cfar[kMode] != RSP_MODE_CA) return fail(RSP_ERR_UNSUPPORTED, "2-D chain: cfarMode must be Cell Averaging");
+    if (uses_gos(c) || c->cfar[kPeakGrouping]) return fail(RSP_ERR_UNSUPPORTED, "2-D chain: CA without peak grouping only");
+    if (R + G > 32) return fail(RSP_ERR_UNSUPPORTED, "2-D chain: range training + guard half-width %d exceeds the 32-cell tile halo", R + G);
   }
   if (c->cfar[kScaler] > 0xFFFFu) return fail(RSP_ERR_INVALID, "thresholdScaler register = 0x%x exceeds protoScaler's 16 bits", c->cfar[kScaler]);
   return RSP_OK;
@@ -303,10 +319,16 @@ int ensure(void** ptr, size_t* have, size_t want) {
 
 size_t beat_bytes(const rsp_chain* c) { return c->p.dtype == RSP_DTYPE_F32 ? 8 : 4; }
 
+int launch_rd(rsp_chain* c, const void* d_in, size_t n_ch, uint32_t* d_out);
+
 int launch_dense(rsp_chain* c, const void* d_in, size_t n_frames, uint32_t* d_out,
                  rsp_detection* d_list = nullptr, uint32_t cap = 0, uint32_t* d_found = nullptr) {
   int rc = check_regs(c);
   if (rc != RSP_OK) return rc;
+  if (c->p.dopplerPoints) {
+    if (d_found) return fail(RSP_ERR_UNSUPPORTED, "2-D chain: use rsp_chain_detections_device on the dense words");
+    return launch_rd(c, d_in, n_frames, d_out);
+  }
   if (n_frames > 0x7fffffffull) return fail(RSP_ERR_INVALID, "n_frames = %zu too large for one call", n_frames);
   if (n_frames && (!d_in || (!d_out && !d_found))) return fail(RSP_ERR_INVALID, "NULL buffer");
   HIP_TRY(hipSetDevice(c->device));
@@ -356,6 +378,36 @@ int launch_dense(rsp_chain* c, const void* d_in, size_t n_frames, uint32_t* d_ou
   if (d_found)
     HIP_TRY(rsp::launch_compact_frames(c->d_fcount, c->d_fdet, (uint32_t)n_frames, d_list, cap,
                                        c->d_count + 1, d_found, c->stream));
+  return RSP_OK;
+}
+
+int launch_rd(rsp_chain* c, const void* d_in, size_t n_ch, uint32_t* d_out) {
+  if (n_ch == 0) return RSP_OK;
+  if (!d_in || !d_out) return fail(RSP_ERR_INVALID, "NULL buffer");
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t cells = (n_ch * (size_t)c->p.dopplerPoints) << c->fft_stages;
+  if (n_ch > 0xffffu || cells > 0x7fffffffull) return fail(RSP_ERR_INVALID, "2-D chain: %zu channels too many for one call", n_ch);
+  int rc = ensure(&c->d_x1, &c->d_x1_bytes, cells * 8);
+  if (rc != RSP_OK) return rc;
+  rc = ensure(reinterpret_cast<void**>(&c->d_mag2), &c->d_mag2_bytes, cells * 4);
+  if (rc != RSP_OK) return rc;
+  rsp::Rd2dLaunch a{};
+  a.in = d_in;
+  a.out = d_out;
+  a.n_ch = (uint32_t)n_ch;
+  a.log2nr = (int)c->fft_stages;
+  a.log2nd = ilog2(c->p.dopplerPoints);
+  a.regs = snapshot(c);
+  a.ref_d = c->p.refDoppler;
+  a.guard_d = c->p.guardDoppler;
+  rc = get_rom(c, a.log2nr, &a.tw_range);
+  if (rc != RSP_OK) return rc;
+  rc = get_rom(c, a.log2nd, &a.tw_doppler);
+  if (rc != RSP_OK) return rc;
+  a.scratch_complex = c->d_x1;
+  a.scratch_mag = c->d_mag2;
+  a.stream = c->stream;
+  HIP_TRY(rsp::launch_rd2d(a));
   return RSP_OK;
 }
 
@@ -468,6 +520,8 @@ void rsp_chain_destroy(rsp_chain* c) {
   if (c->d_count) (void)hipFree(c->d_count);
   if (c->d_fcount) (void)hipFree(c->d_fcount);
   if (c->d_fdet) (void)hipFree(c->d_fdet);
+  if (c->d_x1) (void)hipFree(c->d_x1);
+  if (c->d_mag2) (void)hipFree(c->d_mag2);
   for (auto& pr : c->prof_events) {
     (void)hipEventDestroy(pr.first);
     (void)hipEventDestroy(pr.second);
@@ -544,7 +598,7 @@ int rsp_chain_process(rsp_chain* c, const void* in_beats, size_t n_frames, uint3
   if (n_frames == 0) return RSP_OK;
   if (!in_beats || !out_words) return fail(RSP_ERR_INVALID, "NULL buffer");
   HIP_TRY(hipSetDevice(c->device));
-  const size_t cells = n_frames << c->fft_stages;
+  const size_t cells = (n_frames * (size_t)(c->p.dopplerPoints ? c->p.dopplerPoints : 1)) << c->fft_stages;
   const size_t in_bytes = cells * beat_bytes(c), out_bytes = cells * sizeof(uint32_t);
   rc = ensure(&c->d_in, &c->d_in_bytes, in_bytes);
   if (rc != RSP_OK) return rc;
@@ -563,8 +617,9 @@ int rsp_chain_detections_device(rsp_chain* c, const uint32_t* d_out_words, size_
   if (!c) return fail(RSP_ERR_INVALID, "chain is NULL");
   if (!d_count || (cap && !d_list) || (n_frames && !d_out_words)) return fail(RSP_ERR_INVALID, "NULL buffer");
   HIP_TRY(hipSetDevice(c->device));
-  const uint64_t cells = (uint64_t)n_frames << c->fft_stages;
-  HIP_TRY(rsp::launch_compact(d_out_words, cells, c->fft_stages, 0, d_list, cap, d_count, c->stream));
+  const uint32_t log2_rows = c->p.dopplerPoints ? (uint32_t)ilog2(c->p.dopplerPoints) : 0u;
+  const uint64_t cells = ((uint64_t)n_frames << c->fft_stages) << log2_rows;
+  HIP_TRY(rsp::launch_compact(d_out_words, cells, c->fft_stages, log2_rows, d_list, cap, d_count, c->stream));
   return RSP_OK;
 }
 

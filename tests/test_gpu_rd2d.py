@@ -1,0 +1,87 @@
+"""2-D range-Doppler chain (BASELINE.json configs 3/5; no reference counterpart):
+range FFT -> Doppler FFT -> JPL magnitude -> 2-D CA-CFAR, GPU vs the float64 oracle."""
+import numpy as np
+import pytest
+
+import rsp_chains_amd as R
+from oracle import oracle as O
+from helpers import compare_f32
+
+pytestmark = pytest.mark.gpu
+
+
+def rd_params(nr, nd, ref=8, guard=2, edge="zero"):
+    return R.FftMagCfarVanillaParameters(
+        fftParams=R.FFTParams.fixed(numPoints=nr), magParams=R.MAGParams.fixed(),
+        cfarParams=R.CFARParams(fftSize=nr, leadLaggWindowSize=16, guardWindowSize=4, edgeMode=edge),
+        dtype=R.F32, dopplerPoints=nd, refDoppler=ref, guardDoppler=guard)
+
+
+def targets(n_ch, nd, nr, seed, k=4, sigma=0.05):
+    """Point targets = complex exponentials in fast and slow time + complex white noise."""
+    rng = np.random.default_rng(seed)
+    x = sigma * (rng.standard_normal((n_ch, nd, nr)) + 1j * rng.standard_normal((n_ch, nd, nr)))
+    tr, td = np.arange(nr), np.arange(nd)
+    where = []
+    for ch in range(n_ch):
+        for j in range(k):
+            rb, db = int(rng.integers(0, nr)), int(rng.integers(0, nd))
+            amp = (0.4, 0.2, 0.1, 0.3)[j % 4]
+            x[ch] += amp * np.exp(2j * np.pi * db * td / nd)[:, None] * np.exp(2j * np.pi * rb * tr / nr)[None, :]
+            where.append((ch, db, rb))
+    return x.astype(np.complex64), where
+
+
+@pytest.mark.parametrize("nr,nd,edge", [(256, 256, "zero"), (1024, 512, "zero"), (512, 256, "wrap"), (4096, 512, "zero"),
+                                        (2048, 1024, "zero")])
+def test_rd2d_against_oracle(gpu, nr, nd, edge):
+    n_ch = 2
+    params = rd_params(nr, nd, edge=edge)
+    rt = R.RunTimeRspChainParams(fftSize=nr, CFARMode="Cell Averaging", refWindowSize=8, guardWindowSize=2, divSum=4,
+                                 thresholdScaler=4.0)
+    x, where = targets(n_ch, nd, nr, seed=2345 + nr)
+    with R.FftMagCfarChainVanilla(params) as dut:
+        dut.configure(rt)
+        words = dut.stream(x)
+    assert words.shape == (n_ch, nd, nr)
+    cfg = O.OrcRdCfg(log2nr=R.log2Up(nr), log2nd=R.log2Up(nd), mag_mode=O.MAG_JPL, scaler=4.0, ref_r=8, ref_d=8,
+                     guard_r=2, guard_d=2, edge=1 if edge == "wrap" else 0)
+    thr, peak, margin, mag = O.rd_f32(x, cfg, want_mag=True)
+    compare_f32(words.reshape(n_ch, -1), thr.reshape(n_ch, -1), peak.reshape(n_ch, -1), margin.reshape(n_ch, -1),
+                mag.reshape(n_ch, -1))
+    for ch, db, rb in where:           # every injected target is detected at its (Doppler, range) cell
+        assert words[ch, db, rb] & 1
+
+
+def test_rd2d_detection_list(gpu):
+    nr, nd, n_ch = 512, 256, 3
+    params = rd_params(nr, nd)
+    rt = R.RunTimeRspChainParams(fftSize=nr, CFARMode="Cell Averaging", refWindowSize=8, guardWindowSize=2, divSum=4,
+                                 thresholdScaler=4.0)
+    x, _ = targets(n_ch, nd, nr, seed=77)
+    cap = 1 << 16
+    with R.FftMagCfarChainVanilla(params) as dut:
+        dut.configure(rt)
+        d_in = R.DeviceBuffer(x.nbytes); d_in.upload(x)
+        d_out = R.DeviceBuffer(x.size * 4)
+        d_list, d_cnt = R.DeviceBuffer(cap * 16), R.DeviceBuffer(8)
+        dut.process_device(d_in.ptr, n_ch, d_out.ptr)
+        dut.detections_device(d_out.ptr, n_ch, d_list.ptr, cap, d_cnt.ptr)
+        dut.synchronize()
+        dense = d_out.download(np.uint32, x.size).reshape(n_ch, nd, nr)
+        found = int(d_cnt.download(np.uint32, 1)[0])
+        lst = d_list.download(np.uint32, found * 4).reshape(found, 4)
+    ch, d, r = np.nonzero(dense & 1)
+    want = sorted(zip(ch.tolist(), r.tolist(), d.tolist(), dense[ch, d, r].tolist()))
+    assert sorted(map(tuple, lst.tolist())) == want      # {frame = channel, bin = range, doppler, word}
+
+
+def test_rd2d_rejects_what_it_does_not_implement(gpu):
+    params = rd_params(1024, 512)
+    with R.FftMagCfarChainVanilla(params) as dut:
+        dut.configure(R.RunTimeRspChainParams(fftSize=1024, CFARMode="Greatest Of", refWindowSize=8, guardWindowSize=2, divSum=4))
+        with pytest.raises(NotImplementedError):
+            dut.check()
+    with pytest.raises(NotImplementedError):
+        p = rd_params(1024, 512); p.dtype = R.FIXED16
+        R.FftMagCfarChainVanilla(p)
