@@ -101,7 +101,7 @@ cfar2d_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int hr = ref_r + guard_r, hd = ref_d + guard_d;
   const int RW = kTR + 2 * hr, RH = kTD + 2 * hd;  // haloed region
-  const int MS = RW + 1;                            // row pitch of the magnitude region
+  const int MS = RW | 1;                            // odd row pitch of the magnitude region
   float* m = reinterpret_cast<float*>(smem);        // [RH][MS]
   float* ro = m + RH * MS;                          // outer row sums [RH][kTR + 1]
   float* ri = ro + RH * (kTR + 1);                  // guard row sums [RH][kTR + 1]
@@ -112,26 +112,45 @@ cfar2d_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_
   const int d0 = (int)(t / tiles_r) * kTD, r0 = (int)(t % tiles_r) * kTR;
   const float* map = mag + (size_t)ch * nd * nr;
 
-  // 1. region -> LDS (coalesced along r)
-  for (int i = tid; i < RH * RW; i += 256) {
-    const int rr = i % RW, dd = i / RW;
+  // 1. region -> LDS: 128 lanes across a region row (coalesced along r), 2 rows per iteration
+  {
+    const int rr = tid & 127, half = tid >> 7;
     int r = r0 - hr + rr;
-    const int d = (d0 - hd + dd + (int)nd) & ((int)nd - 1);  // Doppler cyclic (nd is a power of two)
-    float v = 0.f;
     if (edge) r = (r + (int)nr) & ((int)nr - 1);
-    if (r >= 0 && r < (int)nr) v = map[(size_t)d * nr + r];
-    m[dd * MS + rr] = v;
+    const bool inside = rr < RW && r >= 0 && r < (int)nr;
+    // batches of 8 independent loads per thread: a one-load-per-iteration loop serialises on HBM latency
+    for (int base = half; base < RH; base += 16) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int dd = base + 2 * u;
+        const int d = (d0 - hd + dd + (int)nd) & ((int)nd - 1);  // Doppler cyclic (nd is a power of two)
+        v[u] = (inside && dd < RH) ? map[(size_t)d * nr + r] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int dd = base + 2 * u;
+        if (rr < RW && dd < RH) m[dd * MS + rr] = v[u];
+      }
+    }
   }
   __syncthreads();
-  // 2. row pass: sliding sums along r, one task = (region row, run of 16 output columns)
+  // 2. row pass: sliding sums along r; task = (run of 16 output columns, region row), rows on
+  // adjacent lanes: the row pitches (RW + 1, kTR + 1) are odd, so a wave's accesses spread over
+  // all banks
   for (int task = tid; task < RH * (kTR / 16); task += 256) {
-    const int dd = task / (kTR / 16), c0 = (task % (kTR / 16)) * 16;
+    const int dd = task % RH, c0 = (task / RH) * 16;
     const float* row = m + dd * MS + c0 + hr;  // row[c] = cell at output column c0 + c
-    float so = 0.f, si = 0.f;
-    for (int k = -hr; k <= hr; ++k) so += row[k];
-    for (int k = -guard_r; k <= guard_r; ++k) si += row[k];
+    float so = row[0], si = row[0], so2 = 0.f, si2 = 0.f;  // symmetric windows: two independent chains
+#pragma unroll 4
+    for (int k = 1; k <= hr; ++k) { so += row[k]; so2 += row[-k]; }
+#pragma unroll 2
+    for (int k = 1; k <= guard_r; ++k) { si += row[k]; si2 += row[-k]; }
+    so += so2;
+    si += si2;
     float* po = ro + dd * (kTR + 1) + c0;
     float* pi = ri + dd * (kTR + 1) + c0;
+#pragma unroll
     for (int c = 0; c < 16; ++c) {
       po[c] = so;
       pi[c] = si;
@@ -147,10 +166,15 @@ cfar2d_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_
     const float kAc = kA / count;
     const float* co = ro + (dseg + hd) * (kTR + 1) + c;  // co[k (kTR+1)] = outer row sum at output row dseg + k
     const float* ci = ri + (dseg + hd) * (kTR + 1) + c;
-    float so = 0.f, si = 0.f;
-    for (int k = -hd; k <= hd; ++k) so += co[k * (kTR + 1)];
-    for (int k = -guard_d; k <= guard_d; ++k) si += ci[k * (kTR + 1)];
+    float so = co[0], si = ci[0], so2 = 0.f, si2 = 0.f;
+#pragma unroll 4
+    for (int k = 1; k <= hd; ++k) { so += co[k * (kTR + 1)]; so2 += co[-k * (kTR + 1)]; }
+#pragma unroll 2
+    for (int k = 1; k <= guard_d; ++k) { si += ci[k * (kTR + 1)]; si2 += ci[-k * (kTR + 1)]; }
+    so += so2;
+    si += si2;
     uint32_t* dst = out + ((size_t)ch * nd + d0 + dseg) * nr + r0 + c;
+#pragma unroll
     for (int j = 0; j < kTD / 4; ++j) {
       const float thr = __fmaf_rn(so - si, kAc, kB);
       const float cut = m[(dseg + j + hd) * MS + c + hr];
@@ -219,7 +243,7 @@ hipError_t launch_rd2d(const Rd2dLaunch& a) {
   }
   if (e != hipSuccess) return e;
   const int hr = a.regs.R + a.regs.G, hd = a.ref_d + a.guard_d;
-  const size_t lds = 4 * ((size_t)(kTD + 2 * hd) * (kTR + 2 * hr + 1) + 2 * (size_t)(kTD + 2 * hd) * (kTR + 1));
+  const size_t lds = 4 * ((size_t)(kTD + 2 * hd) * ((kTR + 2 * hr) | 1) + 2 * (size_t)(kTD + 2 * hd + 1) * (kTR + 1));
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(cfar2d_kernel),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
