@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--fft", type=int, default=4096)
     ap.add_argument("--chirps", type=int, default=4096)
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"],
+                    help="cfg2 = the headline (BASELINE.json configs[1]); cfg3 / cfg4 are extra lines, same JSON shape")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-json", default=None, help="PMC-derived HBM bytes/launch (profiles/*.json)")
     args = ap.parse_args()
@@ -63,6 +65,8 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
+    if args.workload != "cfg2":
+        return other_workload(args, torch, dist, R, rank, local_rank, world, dev)
     n, frames = args.fft, args.chirps
     cells = n * frames
     params = R.FftMagCfarVanillaParameters(
@@ -178,6 +182,81 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ins[0], n, frames)
         print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def other_workload(args, torch, dist, R, rank, local_rank, world, dev):
+    """cfg3: 8 Rx x 4096 x 512 2-D range-Doppler + 2-D CA-CFAR (28 B/cell algorithmic);
+    cfg4: OS-CFAR (R = 32, k = 24, G = 4) on 8192-point spectra, 2048 chirps (12 B/cell)."""
+    if args.workload == "cfg3":
+        nr, nd, units, bpc = 4096, 512, 8, 28.0
+        params = R.FftMagCfarVanillaParameters(
+            fftParams=R.FFTParams.fixed(numPoints=nr), magParams=R.MAGParams.fixed(),
+            cfarParams=R.CFARParams(fftSize=nr, leadLaggWindowSize=16), dtype=R.F32, device=local_rank,
+            dopplerPoints=nd, refDoppler=8, guardDoppler=2)
+        rt = R.RunTimeRspChainParams(fftSize=nr, CFARMode="Cell Averaging", refWindowSize=8, guardWindowSize=2,
+                                     divSum=4, thresholdScaler=4.0)
+        shape, name = (units, nd, nr), "cfg3: 8-Rx 4096x512 range-Doppler 2-D FFT + JPL logMag + 2-D CA-CFAR (ref 8x8, guard 2x2), fp32"
+        kernel = "range_fft<12> + doppler_mag<9> + cfar2d"
+    else:
+        nr, units, bpc = 8192, 2048, 12.0
+        params = R.FftMagCfarVanillaParameters(
+            fftParams=R.FFTParams.fixed(numPoints=nr), magParams=R.MAGParams.fixed(),
+            cfarParams=R.CFARParams(fftSize=nr, CFARAlgorithm=R.GOSCFARType), dtype=R.F32, device=local_rank)
+        rt = R.RunTimeRspChainParams(fftSize=nr, CFARMode="Greatest Of", refWindowSize=32, guardWindowSize=4, divSum=None,
+                                     indexLagg=24, indexLead=24, thresholdScaler=2.5)
+        shape, name = (units, nr), "cfg4: OS-CFAR (32-cell window, k = 24, G = 4) on 8192-pt spectra, 2048-chirp batch, fp32"
+        kernel = "chain1d_gos_kernel<13,f32>"
+    dut = R.FftMagCfarChainVanilla(params)
+    dut.configure(rt)
+    stream = torch.cuda.current_stream()
+    dut.set_stream(stream.cuda_stream)
+    g = torch.Generator(device=dev)
+    g.manual_seed(2345 + rank)
+    ins = [(0.05 * torch.randn(*shape, 2, device=dev, generator=g)).contiguous() for _ in range(N_SETS)]
+    for x in ins:   # a few strong cells so that the detector has something to find
+        x.view(-1, 2)[:: 65537, 0] += 20.0
+    cells = int(np.prod(shape))
+    outs = [torch.empty(cells, dtype=torch.int32, device=dev) for _ in range(N_SETS)]
+
+    def step(i):
+        dut.process_device(ins[i % N_SETS].data_ptr(), units, outs[i % N_SETS].data_ptr())
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    torch.cuda.synchronize()
+    dut.timer_start()
+    for i in range(args.steps):
+        step(i)
+    kernel_ms = dut.timer_stop() / args.steps
+    if rank == 0:
+        achieved = bpc * cells / (kernel_ms * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "range-Doppler cells/sec (FFT+CFAR)", "value": cells * world * args.steps / elapsed,
+            "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": name, "cells_per_step_per_gpu": cells, "buffer_sets": N_SETS},
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": bpc * cells}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
