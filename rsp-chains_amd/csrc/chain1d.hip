@@ -54,6 +54,7 @@ struct FrameLds {
   static constexpr int CFAR_BYTES = DET_OFF + 8 + 8 * kFrameDetCap;
   static constexpr int FFT_BYTES = 8 * PADN;             // f32x2 per slot (FIXED16 uses 4 B)
   static constexpr int BYTES = ((CFAR_BYTES > FFT_BYTES ? CFAR_BYTES : FFT_BYTES) + 15) & ~15;
+  static constexpr int ROM_BYTES = 4 * (N / 2);  // FIXED16: LDS copy of the Q2.14 twiddle ROM, per workgroup
 };
 
 __device__ __forceinline__ int mag_slot(int x) { return pad(x + 16); }
@@ -131,21 +132,19 @@ template <>
 struct CfarMath<int> {
   static __device__ __forceinline__ int side(int sum, const ChainRegs& rg) { return sum >> rg.div_sum; }
   static __device__ __forceinline__ int half_sum(int a, int b) { return (a + b) >> 1; }
-  static __device__ __forceinline__ long long shr(long long x, int n) { return n >= 0 ? (x >> n) : (x << -n); }
+  // branch-free: both domains computed, selected by the (uniform) logOrLinearMode register.
+  // Ranges: magnitudes are 16-bit, so cut / thr products below fit 32 bits; stat * scaler needs 64.
   static __device__ __forceinline__ uint32_t finish(int stat, int cut, bool group_ok, int k,
                                                     int log2n, const ChainRegs& rg) {
-    long long thr;
-    if (rg.linear) {
-      thr = shr((long long)stat * (long long)rg.scaler_raw, rg.bp_in + rg.bp_scaler - rg.bp_thr);
-    } else {
-      thr = shr((long long)stat, rg.bp_in - rg.bp_thr) +
-            shr((long long)rg.scaler_raw, rg.bp_scaler - rg.bp_thr);
-    }
-    const long long tmax = (1ll << (rg.w_thr - 1)) - 1, tmin = -(1ll << (rg.w_thr - 1));
-    thr = thr > tmax ? tmax : (thr < tmin ? tmin : thr);
-    const uint32_t peak =
-        ((long long)cut * (1ll << rg.bp_thr) > thr * (1ll << rg.bp_in)) && group_ok;
-    return ((uint32_t)(int)thr << (log2n + 1)) | ((uint32_t)k << 1) | peak;
+    const long long prod = ((long long)stat * (long long)rg.scaler_raw) << rg.lin_shl;
+    const long long lin64 = prod >> rg.lin_shr;  // arithmetic: floor, as the spec's trim_shift
+    const int lin = lin64 > (long long)rg.tmax ? rg.tmax : (lin64 < (long long)rg.tmin ? rg.tmin : (int)lin64);
+    int lg = ((stat << rg.log_shl) >> rg.log_shr) + rg.log_scaler;
+    lg = min(max(lg, rg.tmin), rg.tmax);
+    const int thr = rg.linear ? lin : lg;
+    // cut * 2^bp_thr > thr * 2^bp_in, both sides within 31 bits (16-bit values, shifts <= 15)
+    const uint32_t peak = ((cut * (1 << rg.bp_thr)) > (thr * (1 << rg.bp_in))) && group_ok;
+    return ((uint32_t)thr << (log2n + 1)) | ((uint32_t)k << 1) | peak;
   }
 };
 
@@ -166,7 +165,8 @@ template <int M, bool FIXED, typename V>
 __device__ __forceinline__ void front_end(const void* __restrict__ in, uint32_t frame, bool live, int tau,
                                           unsigned char* fbase, const ChainRegs& rg,
                                           const void* __restrict__ tw,
-                                          const int16_t* __restrict__ log_lut, V (&mg)[16]) {
+                                          const int16_t* __restrict__ log_lut, uint32_t* rom,
+                                          V (&mg)[16]) {
   constexpr int N = 1 << M, NP = plan_np(M);
   if constexpr (!FIXED) {
     f32x2* buf = reinterpret_cast<f32x2*>(fbase);
@@ -245,36 +245,45 @@ __device__ __forceinline__ void front_end(const void* __restrict__ in, uint32_t 
         xi[e] = (int)(short)(b & 0xffffu);
       }
     }
-    pass_fx<M, 0>(xr, xi, tau, twq, rg);
-    auto exchange = [&](auto pc) {
-      constexpr int P = decltype(pc)::value;
-      constexpr int W0 = plan_w(M, P - 1), LO0 = plan_lo(M, P - 1);
-      constexpr int W1 = plan_w(M, P), LO1 = plan_lo(M, P);
+    // twiddle ROM -> LDS once per workgroup (the sample loads above are already in flight)
+    for (int i = threadIdx.x; i < N / 2; i += wg_size(M)) rom[i] = twq[i];
+    __syncthreads();
+    auto run = [&](auto conv_c) {
+      constexpr bool CONV = decltype(conv_c)::value;
+      pass_fx<M, 0, CONV>(xr, xi, tau, rom, rg);
+      auto exchange = [&](auto pc) {
+        constexpr int P = decltype(pc)::value;
+        constexpr int W0 = plan_w(M, P - 1), LO0 = plan_lo(M, P - 1);
+        constexpr int W1 = plan_w(M, P), LO1 = plan_lo(M, P);
 #pragma unroll
-      for (int g = 0; g < (16 >> W0); ++g) {
-        uint32_t* b0 = buf + slot_base<M, LO0, W0>(tau, g);
+        for (int g = 0; g < (16 >> W0); ++g) {
+          uint32_t* b0 = buf + slot_base<M, LO0, W0>(tau, g);
 #pragma unroll
-        for (int r = 0; r < (1 << W0); ++r) {
-          const int e = g * (1 << W0) + r;
-          b0[slot_delta<LO0, W0>(r)] = ((uint32_t)xr[e] << 16) | ((uint32_t)xi[e] & 0xffffu);
+          for (int r = 0; r < (1 << W0); ++r) {
+            const int e = g * (1 << W0) + r;
+            b0[slot_delta<LO0, W0>(r)] = ((uint32_t)xr[e] << 16) | ((uint32_t)xi[e] & 0xffffu);
+          }
         }
-      }
-      __syncthreads();
+        __syncthreads();
 #pragma unroll
-      for (int g = 0; g < (16 >> W1); ++g) {
-        const uint32_t* b1 = buf + slot_base<M, LO1, W1>(tau, g);
+        for (int g = 0; g < (16 >> W1); ++g) {
+          const uint32_t* b1 = buf + slot_base<M, LO1, W1>(tau, g);
 #pragma unroll
-        for (int r = 0; r < (1 << W1); ++r) {
-          const uint32_t b = b1[slot_delta<LO1, W1>(r)];
-          xr[g * (1 << W1) + r] = (int)(short)(b >> 16);
-          xi[g * (1 << W1) + r] = (int)(short)(b & 0xffffu);
+          for (int r = 0; r < (1 << W1); ++r) {
+            const uint32_t b = b1[slot_delta<LO1, W1>(r)];
+            xr[g * (1 << W1) + r] = (int)(short)(b >> 16);
+            xi[g * (1 << W1) + r] = (int)(short)(b & 0xffffu);
+          }
         }
-      }
-      pass_fx<M, P>(xr, xi, tau, twq, rg);
+        pass_fx<M, P, CONV>(xr, xi, tau, rom, rg);
+      };
+      exchange(std::integral_constant<int, 1>{});
+      if constexpr (NP > 2) exchange(std::integral_constant<int, 2>{});
+      if constexpr (NP > 3) exchange(std::integral_constant<int, 3>{});
     };
-    exchange(std::integral_constant<int, 1>{});
-    if constexpr (NP > 2) exchange(std::integral_constant<int, 2>{});
-    if constexpr (NP > 3) exchange(std::integral_constant<int, 3>{});
+    // convergent (the default trim) has a 3-op closed form; floor / half-up share the generic one
+    if (rg.trim_conv) run(std::true_type{});
+    else run(std::false_type{});
     if (rg.mag_mode == 2) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) mg[e] = jpl_fx(xr[e], xi[e]);
@@ -363,7 +372,8 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
   unsigned char* fbase = smem + fl * L::BYTES;
 
   V mg[16];
-  front_end<M, FIXED, V>(in, frame, live, tau, fbase, rg, tw, log_lut, mg);
+  front_end<M, FIXED, V>(in, frame, live, tau, fbase, rg, tw, log_lut,
+                         reinterpret_cast<uint32_t*>(smem + (size_t)L::BYTES * FPW), mg);
 
   // ---- magnitudes to LDS in natural bin order ----
   V* mag = reinterpret_cast<V*>(fbase + L::MAG_OFF);
@@ -629,7 +639,8 @@ chain1d_gos_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint
   unsigned char* fbase = smem + (size_t)fl * lay.frame_bytes;
 
   V mg[16];
-  front_end<M, FIXED, V>(in, frame, live, tau, fbase, rg, tw, log_lut, mg);
+  front_end<M, FIXED, V>(in, frame, live, tau, fbase, rg, tw, log_lut,
+                         reinterpret_cast<uint32_t*>(smem + (size_t)lay.frame_bytes * FPW), mg);
 
   V* mag = reinterpret_cast<V*>(fbase);  // cell x in [-256, N + 256] at slot pad(x + 256)
   V* o1 = reinterpret_cast<V*>(fbase + lay.o1_off);
@@ -705,7 +716,7 @@ static hipError_t launch_gos(const Chain1dLaunch& a) {
   const uint32_t fpw = frames_per_wg(M);
   const uint32_t grid = (a.n_frames + fpw - 1) / fpw;
   const GosLayout lay = gos_layout<M>(a.regs);
-  const size_t lds = (size_t)lay.frame_bytes * fpw;
+  const size_t lds = (size_t)lay.frame_bytes * fpw + (a.fixed ? FrameLds<M>::ROM_BYTES : 0);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   hipError_t e;
   if (a.fixed) {
@@ -729,7 +740,7 @@ static hipError_t launch_m(const Chain1dLaunch& a) {
   if (a.regs.algorithm == 1) return launch_gos<M>(a);
   const uint32_t fpw = frames_per_wg(M);
   const uint32_t grid = (a.n_frames + fpw - 1) / fpw;
-  size_t lds = FrameLds<M>::BYTES * fpw;
+  size_t lds = FrameLds<M>::BYTES * fpw + (a.fixed ? FrameLds<M>::ROM_BYTES : 0);
   if (const char* ex = getenv("RSP_DEBUG_EXTRA_LDS")) lds += (size_t)atoi(ex);  // occupancy experiments only
   if (a.fixed) {
     auto k = chain1d_kernel<M, true>;

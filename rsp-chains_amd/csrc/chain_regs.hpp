@@ -19,6 +19,10 @@ struct ChainRegs {
   float div_f;      // F32 path: 2^-divSum
   int32_t linear, div_sum, peak_grouping, algorithm, cfar_mode;
   int32_t R, G, idx_lagg, idx_lead, sub_window, edge;
+  // FIXED16 threshold arithmetic, pre-split on the host so the kernel needs no sign tests:
+  // linear: thr = ((stat * scaler) << lin_shl) >> lin_shr   (one of the two is 0)
+  // log:    thr = ((stat << log_shl) >> log_shr) + log_scaler
+  int32_t lin_shl, lin_shr, log_shl, log_shr, log_scaler, tmax, tmin;
 };
 
 constexpr int kMinLog2N = 8;   // LDS scan rows are 16 lanes x 16 cells = 256 cells

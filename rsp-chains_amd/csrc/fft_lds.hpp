@@ -220,21 +220,29 @@ __device__ __forceinline__ int bin_of(int tau, int g, int p) {
 
 // ---------------------------------------------------------------- FIXED16 pieces
 
-// arithmetic >> n with the FFT trim type (oracle: trim_shift)
+// arithmetic >> n with the FFT trim type (oracle: trim_shift).
+// Generic form: bias 0 (floor) or 2^(n-1); convergent clears the LSB on an exact tie.
 __device__ __forceinline__ int trim_n(int x, int n, int bias, int conv) {
   const int t = x + bias;
   int r = t >> n;
   const int tie = ((t & ((1 << n) - 1)) == 0) ? conv : 0;
   return r & ~tie;
 }
+// Convergent (the default) in 3 ops: round-half-even(x / 2^n) = (x + 2^(n-1) - 1 + ((x >> n) & 1)) >> n
+template <int NBITS>
+__device__ __forceinline__ int trim_conv(int x) {
+  return (x + ((1 << (NBITS - 1)) - 1) + ((x >> NBITS) & 1)) >> NBITS;
+}
 __device__ __forceinline__ int wrap16(int x) { return (int)(short)x; }
 
 // One register pass of the fixed-point FFT: radix-2 stages of field [LO, LO+W),
 // each with its own Q2.14 twiddle, (a+b) trimmed by 1 bit, (a-b)*W by 15 bits.
-// tw[k] = (wr << 16) | (wi & 0xffff) for W_N^k, k < N/2.
-template <int M, int P>
-__device__ __forceinline__ void pass_fx(int (&xr)[16], int (&xi)[16], int tau,
-                                        const uint32_t* __restrict__ tw, const ChainRegs& rg) {
+// tw[k] = (wr << 16) | (wi & 0xffff) for W_N^k, k < N/2 -- an LDS copy of the ROM: for a given
+// stage and butterfly the index is (per-thread low << s) + compile-time constant, so every lookup
+// is one ds_read_b32 with an immediate offset.
+template <int M, int P, bool CONV>
+__device__ __forceinline__ void pass_fx(int (&xr)[16], int (&xi)[16], int tau, const uint32_t* tw,
+                                        const ChainRegs& rg) {
   constexpr int W = plan_w(M, P), LO = plan_lo(M, P), G = 16 >> W, T = threads_per_frame(M);
 #pragma unroll
   for (int g = 0; g < G; ++g) {
@@ -243,23 +251,30 @@ __device__ __forceinline__ void pass_fx(int (&xr)[16], int (&xi)[16], int tau,
     for (int st = 0; st < W; ++st) {
       const int bl = W - 1 - st;
       const int s = M - 1 - (LO + bl);  // radix-2 stage number of this bit
+      const uint32_t* tws = tw + (low << s);
 #pragma unroll
       for (int r0 = 0; r0 < (1 << W); ++r0) {
         if (r0 & (1 << bl)) continue;
         const int r1 = r0 | (1 << bl);
         const int jj = r0 & ((1 << bl) - 1);
-        const int e = ((jj << LO) | low) << s;
-        const uint32_t w = tw[e];
+        const uint32_t w = tws[(jj << LO) << s];
         const int wr = (int)(short)(w >> 16), wi = (int)(short)(w & 0xffffu);
         const int ia = g * (1 << W) + r0, ib = g * (1 << W) + r1;
         const int sr = xr[ia] + xr[ib], si = xi[ia] + xi[ib];
         const int dr = xr[ia] - xr[ib], di = xi[ia] - xi[ib];
         const int pr = __mul24(dr, wr) - __mul24(di, wi);
         const int pi = __mul24(dr, wi) + __mul24(di, wr);
-        xr[ia] = wrap16(trim_n(sr, 1, rg.trim_bias1, rg.trim_conv));
-        xi[ia] = wrap16(trim_n(si, 1, rg.trim_bias1, rg.trim_conv));
-        xr[ib] = wrap16(trim_n(pr, 15, rg.trim_bias15, rg.trim_conv));
-        xi[ib] = wrap16(trim_n(pi, 15, rg.trim_bias15, rg.trim_conv));
+        if constexpr (CONV) {
+          xr[ia] = wrap16(trim_conv<1>(sr));
+          xi[ia] = wrap16(trim_conv<1>(si));
+          xr[ib] = wrap16(trim_conv<15>(pr));
+          xi[ib] = wrap16(trim_conv<15>(pi));
+        } else {
+          xr[ia] = wrap16(trim_n(sr, 1, rg.trim_bias1, 0));
+          xi[ia] = wrap16(trim_n(si, 1, rg.trim_bias1, 0));
+          xr[ib] = wrap16(trim_n(pr, 15, rg.trim_bias15, 0));
+          xi[ib] = wrap16(trim_n(pi, 15, rg.trim_bias15, 0));
+        }
       }
     }
   }

@@ -270,6 +270,18 @@ rsp::ChainRegs snapshot(const rsp_chain* c) {
   if (const char* m = getenv("RSP_ABLATE_MASK")) r.sub_window = atoi(m);
 #endif
   r.edge = p.cfarParams.edgeMode;
+  {
+    const int lin = r.bp_in + r.bp_scaler - r.bp_thr;  // oracle: trim_shift(stat * scaler, lin)
+    r.lin_shr = lin > 0 ? lin : 0;
+    r.lin_shl = lin < 0 ? -lin : 0;
+    const int lg = r.bp_in - r.bp_thr;
+    r.log_shr = lg > 0 ? lg : 0;
+    r.log_shl = lg < 0 ? -lg : 0;
+    const int ls = r.bp_scaler - r.bp_thr;
+    r.log_scaler = ls >= 0 ? (int32_t)(r.scaler_raw >> ls) : (int32_t)(r.scaler_raw << -ls);
+    r.tmax = (1 << (r.w_thr - 1)) - 1;
+    r.tmin = -(1 << (r.w_thr - 1));
+  }
   return r;
 }
 
