@@ -32,7 +32,8 @@ class OrcCfg(C.Structure):
 class OrcFCfg(C.Structure):
     _fields_ = [("log2n", C.c_int32), ("mag_mode", C.c_int32), ("scaler", C.c_double)] + [
         (n, C.c_int32) for n in ("linear", "div_sum", "peak_grouping", "algorithm", "cfar_mode",
-                                 "ref_window", "guard_window", "index_lagg", "index_lead", "edge")]
+                                 "ref_window", "guard_window", "index_lagg", "index_lead", "edge",
+                                 "sub_window")]
 
 
 class OrcRdCfg(C.Structure):
@@ -108,7 +109,7 @@ def default_cfg(**kw) -> OrcCfg:
 def default_fcfg(**kw) -> OrcFCfg:
     c = OrcFCfg(log2n=12, mag_mode=MAG_JPL, scaler=3.5, linear=1, div_sum=5, peak_grouping=0,
                 algorithm=0, cfar_mode=CFAR_CA, ref_window=32, guard_window=4, index_lagg=0,
-                index_lead=0, edge=EDGE_ZERO)
+                index_lead=0, edge=EDGE_ZERO, sub_window=0)
     for k, v in kw.items():
         setattr(c, k, v)
     return c

@@ -381,6 +381,17 @@ void orc_cfar_f64(const double* mag, const orc_fcfg* c, double* thr, uint8_t* pe
         int idx = side == 0 ? c->index_lagg : c->index_lead;
         qsort(win, (size_t)R, sizeof(double), cmp_f64);
         side_stat[side] = win[idx];
+      } else if (c->cfar_mode == ORC_CFAR_CASH) { /* same rule as the fixed-point path */
+        int sw = c->sub_window > 0 ? c->sub_window : R;
+        double best = 0.0;
+        int first = 1;
+        for (int s0 = 0; s0 + sw <= R; s0 += sw) {
+          double ss = 0.0;
+          for (int d = 0; d < sw; d++) ss += win[s0 + d];
+          if (first || ss > best) best = ss;
+          first = 0;
+        }
+        side_stat[side] = best * div;
       } else {
         side_stat[side] = sum * div;
       }

@@ -107,6 +107,7 @@ typedef struct orc_fcfg {
   int32_t index_lagg;
   int32_t index_lead;
   int32_t edge;
+  int32_t sub_window; /* CASH only */
 } orc_fcfg;
 
 /* Forward FFT with the same net 1/N scaling, in float64. interleaved re,im. */

@@ -475,7 +475,30 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
         const V cut = pm[JS * j];
         bool group_ok = true;
         if constexpr (GROUP) group_ok = cut > pm[JS * j - dl] && cut > pm[JS * j + dr];
-        if constexpr (!FIXED) {
+        if constexpr (MODE == 3) {
+          // CASH (cfarMode 3, CACFARType with includeCASH): each window is cut into sub-windows of
+          // subWindowSize cells; per side the largest sub-window sum, then the smaller side
+          // (BUILD-DEFINED, oracle/rsp_oracle.c orc_cfar_fixed).  Sub-window sums are prefix
+          // differences like the whole-window sums, with the block fix-up computed per access.
+          const int k = tau + T * j;
+          V best[2];
+#pragma unroll
+          for (int side = 0; side < 2; ++side) {
+            const int a = side == 0 ? k - G - R : k + G + 1;
+            V b = V(0);
+            bool first = true;
+            for (int s0 = 0; s0 + rg.sub_window <= R; s0 += rg.sub_window) {
+              const int u = a + s0, v = u + rg.sub_window;
+              V ss = pb[pb_slot(v)] - pb[pb_slot(u)];
+              if ((v >> 8) != (u >> 8)) ss += bs[u >> 8];
+              b = first ? ss : (ss > b ? ss : b);
+              first = false;
+            }
+            best[side] = b;
+          }
+          const V stat = CfarMath<V>::side(best[0] < best[1] ? best[0] : best[1], rg);
+          word[j] = CfarMath<V>::finish(stat, cut, group_ok, k, M, rg);
+        } else if constexpr (!FIXED) {
           // both windows in one packed subtract / fma; divSum, the 1/2 of CA and the scaler are
           // folded into kA (powers of two except the scaler: the same single rounding as the spec)
           const f32x2 pv = {pv0[JS * j], pv1[JS * j]}, pu = {pu0[JS * j], pu1[JS * j]};
@@ -506,17 +529,20 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
     if (ABL(1)) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) word[j] = __builtin_bit_cast(uint32_t, pm[JS * j]);
     } else if (rg.peak_grouping) {
       if (rg.cfar_mode == 0) cells(I0{}, std::true_type{});
       else if (rg.cfar_mode == 1) cells(I1{}, std::true_type{});
-      else cells(I2{}, std::true_type{});
+      else if (rg.cfar_mode == 2) cells(I2{}, std::true_type{});
+      else cells(I3{}, std::true_type{});
     } else {
       if (rg.cfar_mode == 0) cells(I0{}, std::false_type{});
       else if (rg.cfar_mode == 1) cells(I1{}, std::false_type{});
-      else cells(I2{}, std::false_type{});
+      else if (rg.cfar_mode == 2) cells(I2{}, std::false_type{});
+      else cells(I3{}, std::false_type{});
     }
   }
   emit_words<M>(word, out, frame, live, tau, det_cnt, det_stage, fcount, fdet);

@@ -118,17 +118,17 @@ cfar2d_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_
     int r = r0 - hr + rr;
     if (edge) r = (r + (int)nr) & ((int)nr - 1);
     const bool inside = rr < RW && r >= 0 && r < (int)nr;
-    // batches of 8 independent loads per thread: a one-load-per-iteration loop serialises on HBM latency
-    for (int base = half; base < RH; base += 16) {
-      float v[8];
+    // batches of 16 independent loads per thread: a one-load-per-iteration loop serialises on HBM latency
+    for (int base = half; base < RH; base += 32) {
+      float v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 16; ++u) {
         const int dd = base + 2 * u;
         const int d = (d0 - hd + dd + (int)nd) & ((int)nd - 1);  // Doppler cyclic (nd is a power of two)
         v[u] = (inside && dd < RH) ? map[(size_t)d * nr + r] : 0.f;
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 16; ++u) {
         const int dd = base + 2 * u;
         if (rr < RW && dd < RH) m[dd * MS + rr] = v[u];
       }

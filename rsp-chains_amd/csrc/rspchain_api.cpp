@@ -215,7 +215,11 @@ int check_regs(const rsp_chain* c) {
   if (c->cfar[kMode] == RSP_MODE_CASH) {
     if (!(p.cfarParams.CFARAlgorithm == RSP_ALG_CA && p.cfarParams.includeCASH))
       return fail(RSP_ERR_INVALID, "cfarMode = CASH needs CACFARType with includeCASH = true");
-    return fail(RSP_ERR_UNSUPPORTED, "cfarMode = CASH is not implemented on the GPU path yet");
+    const int sub = (int)c->cfar[kSubWindow];
+    if (sub <= 0 || sub >= R) return fail(RSP_ERR_INVALID, "subWindowSize = %d must lie in 1..refWindowSize-1", sub);
+    if (p.cfarParams.minSubWindowSize > 0 && sub < p.cfarParams.minSubWindowSize)
+      return fail(RSP_ERR_INVALID, "subWindowSize = %d < minSubWindowSize = %d", sub, p.cfarParams.minSubWindowSize);
+    if (p.dopplerPoints) return fail(RSP_ERR_UNSUPPORTED, "2-D chain: CASH is not defined");
   }
   if (cfar_reg_present(p, kDivSum) && c->cfar[kDivSum] > 15) return fail(RSP_ERR_INVALID, "divSum = %u", c->cfar[kDivSum]);
   if (cfar_reg_present(p, kIndexLagg)) {

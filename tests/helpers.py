@@ -48,7 +48,7 @@ def oracle_fcfg(params, rt):
         peak_grouping=rt.peakGrouping, algorithm=1 if gos else 0,
         cfar_mode={v: k for k, v in MODE_NAMES.items()}[rt.CFARMode], ref_window=rt.refWindowSize,
         guard_window=rt.guardWindowSize, index_lagg=rt.indexLagg or 0, index_lead=rt.indexLead or 0,
-        edge={"zero": 0, "wrap": 1}[c.edgeMode])
+        edge={"zero": 0, "wrap": 1}[c.edgeMode], sub_window=rt.subWindowSize or 0)
 
 
 def random_beats(n_frames, n, seed, amp=12000):

@@ -271,3 +271,34 @@ def test_f32_gos(gpu, n, ref, idx):
     thr, peak, margin, mag = O.chain_f32(x, oracle_fcfg(params, rt), want_mag=True)
     compare_f32(words, thr, peak, margin, mag)
     assert np.all((words & 1).sum(axis=1) >= 3)
+
+
+@pytest.mark.parametrize("n,ref,sub,edge", [(1024, 32, 8, "zero"), (512, 16, 4, "wrap"), (4096, 64, 16, "zero"), (256, 8, 2, "zero")])
+def test_cash_mode(gpu, n, ref, sub, edge):
+    """cfarMode 3 = CASH on a CACFARType build with includeCASH = true: the subWindowSize register
+    at offset 0x2C exists only then (FftMagCfarChainTester.scala:129-132).  FIXED16 bit-exact, F32 in tolerance."""
+    params = make_params(n, includeCASH=True, edge=edge)
+    rt = R.RunTimeRspChainParams(fftSize=n, CFARMode="CASH", refWindowSize=ref, guardWindowSize=2, subWindowSize=sub,
+                                 divSum=R.log2Up(sub), thresholdScaler=3.0, peakGrouping=1 if sub == 4 else 0)
+    beats = np.concatenate([tone_beats(2, n, 31), random_beats(2, n, 32)])
+    got = run_fixed(params, rt, beats)
+    assert np.array_equal(got, O.chain_fixed(beats, oracle_cfg(params, rt)).reshape(got.shape))
+    paramsf = make_params(n, dtype=R.F32, includeCASH=True, edge=edge)
+    x = R.stimulus.chirp_frames(3, n, seed=44)
+    with R.FftMagCfarChainVanilla(paramsf) as dut:
+        dut.configure(rt)
+        words = dut.stream(x)
+    thr, peak, margin, mag = O.chain_f32(x, oracle_fcfg(paramsf, rt), want_mag=True)
+    # short sub-window sums are differences of block prefixes up to 256 cells long: fp32 cancellation
+    # ~ 6e-8 * 256 / subWindowSize, so CASH is held to 5e-5 (< the reference's 2-LSB = 6e-5 of full scale)
+    compare_f32(words, thr, peak, margin, mag, rtol=5e-5)
+
+
+def test_cash_register_only_exists_with_includeCASH(gpu):
+    with R.FftMagCfarChainVanilla(make_params(1024)) as dut:
+        with pytest.raises(IndexError):
+            dut.memWriteWord(0x30002000 + 11 * 4, 8)
+        dut.configure(R.RunTimeRspChainParams())
+        dut.memWriteWord(0x30002000 + 6 * 4, 3)          # cfarMode = CASH on a build without it
+        with pytest.raises(ValueError):
+            dut.check()
