@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--fft", type=int, default=4096)
     ap.add_argument("--chirps", type=int, default=4096)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"],
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
                     help="cfg2 = the headline (BASELINE.json configs[1]); cfg3 / cfg4 are extra lines, same JSON shape")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-json", default=None, help="PMC-derived HBM bytes/launch (profiles/*.json)")
@@ -98,6 +98,7 @@ def main():
         lists.append(torch.empty(cap, 4, dtype=torch.int32, device=dev))
         counts.append(torch.zeros(1, dtype=torch.int32, device=dev))
     if world > 1:
+        from rsp_chains_amd.dist import gather_detections
         comm_stream = torch.cuda.Stream(device=dev)
         g_lists = [torch.empty(world * cap, 4, dtype=torch.int32, device=dev) for _ in range(N_SETS)]
         g_counts = [torch.empty(world, dtype=torch.int32, device=dev) for _ in range(N_SETS)]
@@ -114,8 +115,7 @@ def main():
             ready[s].record(main_stream)
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(ready[s])
-                dist.all_gather_into_tensor(g_counts[s], counts[s])
-                dist.all_gather_into_tensor(g_lists[s], lists[s])
+                gather_detections(lists[s], counts[s], cap, out_list=g_lists[s], out_counts=g_counts[s])
                 gathered[s].record(comm_stream)
 
     def fence():
@@ -189,16 +189,19 @@ def main():
 def other_workload(args, torch, dist, R, rank, local_rank, world, dev):
     """cfg3: 8 Rx x 4096 x 512 2-D range-Doppler + 2-D CA-CFAR (28 B/cell algorithmic);
     cfg4: OS-CFAR (R = 32, k = 24, G = 4) on 8192-point spectra, 2048 chirps (12 B/cell)."""
-    if args.workload == "cfg3":
-        nr, nd, units, bpc = 4096, 512, 8, 28.0
+    if args.workload in ("cfg3", "cfg5"):
+        nr, nd, units, bpc = (4096, 512, 8, 28.0) if args.workload == "cfg3" else (8192, 1024, 8, 28.0)
         params = R.FftMagCfarVanillaParameters(
             fftParams=R.FFTParams.fixed(numPoints=nr), magParams=R.MAGParams.fixed(),
             cfarParams=R.CFARParams(fftSize=nr, leadLaggWindowSize=16), dtype=R.F32, device=local_rank,
             dopplerPoints=nd, refDoppler=8, guardDoppler=2)
         rt = R.RunTimeRspChainParams(fftSize=nr, CFARMode="Cell Averaging", refWindowSize=8, guardWindowSize=2,
                                      divSum=4, thresholdScaler=4.0)
-        shape, name = (units, nd, nr), "cfg3: 8-Rx 4096x512 range-Doppler 2-D FFT + JPL logMag + 2-D CA-CFAR (ref 8x8, guard 2x2), fp32"
-        kernel = "range_fft<12> + doppler_mag<9> + cfar2d"
+        shape = (units, nd, nr)
+        name = (f"{args.workload}: 8 Rx per GPU, {nr}x{nd} range-Doppler 2-D FFT + JPL logMag + 2-D CA-CFAR "
+                "(ref 8x8, guard 2x2), fp32, dense words + compact detection list"
+                + ("; Rx channels sharded over ranks, RCCL all-gather of the lists" if args.workload == "cfg5" else ""))
+        kernel = f"range_fft<{nr.bit_length() - 1}> + doppler_mag<{nd.bit_length() - 1}> + cfar2d"
     else:
         nr, units, bpc = 8192, 2048, 12.0
         params = R.FftMagCfarVanillaParameters(
@@ -219,9 +222,31 @@ def other_workload(args, torch, dist, R, rank, local_rank, world, dev):
         x.view(-1, 2)[:: 65537, 0] += 20.0
     cells = int(np.prod(shape))
     outs = [torch.empty(cells, dtype=torch.int32, device=dev) for _ in range(N_SETS)]
+    cap = 1 << 16
+    lists = [torch.empty(cap, 4, dtype=torch.int32, device=dev) for _ in range(N_SETS)]
+    counts = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(N_SETS)]
+    gather = args.workload == "cfg5" and world > 1
+    if gather:
+        from rsp_chains_amd.dist import gather_detections
+        comm = torch.cuda.Stream(device=dev)
+        g_lists = [torch.empty(world * cap, 4, dtype=torch.int32, device=dev) for _ in range(N_SETS)]
+        g_counts = [torch.empty(world, dtype=torch.int32, device=dev) for _ in range(N_SETS)]
+        ready = [torch.cuda.Event() for _ in range(N_SETS)]
+        gathered = [torch.cuda.Event() for _ in range(N_SETS)]
 
     def step(i):
-        dut.process_device(ins[i % N_SETS].data_ptr(), units, outs[i % N_SETS].data_ptr())
+        s = i % N_SETS
+        if gather and i >= N_SETS:
+            stream.wait_event(gathered[s])
+        dut.process_device(ins[s].data_ptr(), units, outs[s].data_ptr())
+        if args.workload == "cfg5":
+            dut.detections_device(outs[s].data_ptr(), units, lists[s].data_ptr(), cap, counts[s].data_ptr())
+        if gather:
+            ready[s].record(stream)
+            with torch.cuda.stream(comm):
+                comm.wait_event(ready[s])
+                gather_detections(lists[s], counts[s], cap, out_list=g_lists[s], out_counts=g_counts[s])
+                gathered[s].record(comm)
 
     def fence():
         torch.cuda.synchronize()
