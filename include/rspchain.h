@@ -215,6 +215,44 @@ int rsp_device_free(int device, void* ptr);
 int rsp_memcpy_h2d(int device, void* dst, const void* src, size_t bytes);
 int rsp_memcpy_d2h(int device, void* dst, const void* src, size_t bytes);
 
+/* --- PLFG -> NCO stimulus of the full chain (RspChainVanilla) ----------------------------------
+ * Replaces PLFGDspBlockMem + AXI4NCOLazyModuleBlock (src/main/scala/RspChain.scala:41-42) and the
+ * wiring nco.freq := plfg.streamNode, fft.streamNode := nco.streamNode (:57-58): generates the
+ * chain's input beats on the device instead of reading them from HBM.  Generator sources are
+ * empty submodules, so the model is build-defined (spelled out in DESIGN.md), anchored on
+ * the parameter sets (RspChain.scala:84-106) and the tester's register program
+ * (src/test/scala/RspChainVanillaTester.scala:80-94). */
+typedef struct rsp_plfg_params { /* FixedPLFGParams, RspChain.scala:84-93 */
+  int32_t maxNumOfSegments, maxNumOfDifferentChirps, maxNumOfRepeatedChirps, maxChirpOrdinalNum,
+      maxNumOfFrames, maxNumOfSamplesWidth, outputWidthInt, outputWidthFrac;
+} rsp_plfg_params;
+typedef struct rsp_nco_params { /* FixedNCOParams, RspChain.scala:94-106 */
+  int32_t tableSize, tableWidth, phaseWidth, rasterizedMode, nInterpolationTerms, ditherEnable,
+      syncROMEnable, phaseAccEnable, roundingMode /* 0 = RoundHalfUp */, pincType /* 0 = Streaming */,
+      poffType /* 0 = Fixed */;
+} rsp_nco_params;
+typedef struct rsp_stimulus_params {
+  rsp_plfg_params plfgParams;
+  rsp_nco_params ncoParams;
+  rsp_address_set plfgAddress; /* RspChain.scala:141 */
+  rsp_address_set plfgRAM;     /* :142 */
+  rsp_address_set ncoAddress;  /* :143 */
+  int32_t beatBytes;
+  int32_t device;
+} rsp_stimulus_params;
+typedef struct rsp_stimulus rsp_stimulus;
+void rsp_stimulus_default_params(rsp_stimulus_params* p); /* RspChainVanillaApp, RspChain.scala:83-106,141-143 */
+int rsp_stimulus_create(const rsp_stimulus_params* p, rsp_stimulus** out);
+void rsp_stimulus_destroy(rsp_stimulus* s);
+/* PLFG registers / RAM words: RspChainVanillaTester.scala:80-94 (offsets in beats: 0 enable,
+ * 1 reset, 2 frames, 4 chirps, 5 start value, 6.. segments per chirp type, +4.. repeats, +8.. ordinals) */
+int rsp_stimulus_write_reg(rsp_stimulus* s, uint32_t addr, uint32_t value);
+int rsp_stimulus_read_reg(rsp_stimulus* s, uint32_t addr, uint32_t* value);
+/* n_samples beats {cos[31:16], sin[15:0]} from reset, into device / host memory */
+int rsp_stimulus_generate_device(rsp_stimulus* s, uint32_t* d_beats, size_t n_samples, void* hip_stream);
+int rsp_stimulus_generate(rsp_stimulus* s, uint32_t* beats, size_t n_samples);
+const char* rsp_stimulus_last_error(void);
+
 /* --- wire-format helpers ---------------------------------------------------- */
 /* formAXI4StreamComplexData, RspChainTesterUtils.scala:105-109 */
 uint32_t rsp_pack_iq(int32_t re, int32_t im);

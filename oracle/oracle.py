@@ -42,6 +42,13 @@ class OrcRdCfg(C.Structure):
                     "ref_r", "ref_d", "guard_r", "guard_d", "edge")]
 
 
+class OrcStimCfg(C.Structure):
+    _fields_ = [("enable", C.c_int32), ("start_value", C.c_int32), ("num_chirps", C.c_int32),
+                ("max_segments", C.c_int32), ("segment_nums", C.c_int32 * 8), ("repeated", C.c_int32 * 8),
+                ("ordinal", C.c_int32 * 8), ("ram", C.c_uint32 * 64), ("table_size", C.c_int32),
+                ("table_width", C.c_int32), ("phase_width", C.c_int32)]
+
+
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (Makefile beside this file)."""
     src = os.path.join(_HERE, "rsp_oracle.c")
@@ -85,6 +92,8 @@ def lib():
                                       C.c_void_p, C.c_void_p, C.c_int]
         L.orc_rd_f32in.argtypes = [C.c_void_p, C.c_size_t, P(OrcRdCfg), C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_plfg.argtypes = [P(OrcStimCfg), C.c_size_t, C.c_void_p]
+        L.orc_plfg_nco.argtypes = [P(OrcStimCfg), C.c_size_t, C.c_void_p]
         _lib = L
     return _lib
 
@@ -221,3 +230,25 @@ def rd_f32(x, cfg: OrcRdCfg, n_threads: int = 1, want_mag: bool = False):
     lib().orc_rd_f32in(_p(x), ch, C.byref(cfg), _p(thr), _p(peak), _p(margin),
                        _p(mag) if want_mag else None, n_threads)
     return (thr, peak, margin, mag) if want_mag else (thr, peak, margin)
+
+
+def tester_stim_cfg(start_value=16, ram0=0x24000000, **kw) -> OrcStimCfg:
+    """The PLFG program RspChainVanillaTester.scala:86-94 writes + FixedNCOParams of RspChain.scala:94-106."""
+    c = OrcStimCfg(enable=1, start_value=start_value, num_chirps=1, max_segments=4, table_size=128, table_width=16,
+                   phase_width=9)
+    c.segment_nums[0], c.repeated[0], c.ordinal[0], c.ram[0] = 1, 1, 0, ram0
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def plfg(cfg: OrcStimCfg, n: int) -> np.ndarray:
+    v = np.zeros(n, np.int32)
+    lib().orc_plfg(C.byref(cfg), n, _p(v))
+    return v
+
+
+def plfg_nco(cfg: OrcStimCfg, n: int) -> np.ndarray:
+    b = np.zeros(n, np.uint32)
+    lib().orc_plfg_nco(C.byref(cfg), n, _p(b))
+    return b

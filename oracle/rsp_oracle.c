@@ -532,3 +532,66 @@ void orc_rd_f32in(const float* in, size_t n_ch, const orc_rdcfg* c, double* thr,
   free(twr);
   free(twd);
 }
+
+/* ------------------------------------------------------------------ PLFG -> NCO stimulus */
+
+void orc_plfg(const orc_stim_cfg* c, size_t n, int32_t* values) {
+  size_t i = 0;
+  if (!c->enable) {
+    for (; i < n; i++) values[i] = 0;
+    return;
+  }
+  while (i < n) {
+    size_t before = i;
+    for (int ch = 0; ch < c->num_chirps && i < n; ch++) {
+      int o = c->ordinal[ch];
+      for (int rep = 0; rep < c->repeated[ch] && i < n; rep++) {
+        int32_t v = c->start_value;
+        for (int sg = 0; sg < c->segment_nums[o] && i < n; sg++) {
+          uint32_t w = c->ram[o * c->max_segments + sg];
+          int len = (int)(w >> 24);
+          int32_t slope = (int32_t)((w >> 8) & 0xFFFF);
+          if (w & 2u) slope = -slope;
+          if (w & 1u) v = c->start_value;
+          for (int k = 0; k < len && i < n; k++) {
+            values[i++] = v;
+            v += slope;
+          }
+        }
+      }
+    }
+    if (i == before) { /* empty program: hold the start value */
+      for (; i < n; i++) values[i] = c->start_value;
+    }
+  }
+}
+
+static int32_t nco_quarter(const orc_stim_cfg* c, int k) { /* k in 0..table_size */
+  double v = sin(2.0 * M_PI * (double)k / (4.0 * (double)c->table_size)) * ldexp(1.0, c->table_width - 2);
+  return (int32_t)floor(v + 0.5);
+}
+
+static int32_t nco_sin(const orc_stim_cfg* c, uint32_t phase) {
+  uint32_t ts = (uint32_t)c->table_size, q = phase / ts, r = phase % ts;
+  switch (q & 3u) {
+    case 0: return nco_quarter(c, (int)r);
+    case 1: return nco_quarter(c, (int)(ts - r));
+    case 2: return -nco_quarter(c, (int)r);
+    default: return -nco_quarter(c, (int)(ts - r));
+  }
+}
+
+void orc_plfg_nco(const orc_stim_cfg* c, size_t n, uint32_t* beats) {
+  int32_t* v = (int32_t*)malloc(sizeof(int32_t) * (n ? n : 1));
+  orc_plfg(c, n, v);
+  uint32_t mask = (1u << c->phase_width) - 1u, phase = 0;
+  for (size_t i = 0; i < n; i++) {
+    phase = (phase + (uint32_t)v[i]) & mask;
+    int32_t sn = nco_sin(c, phase), cs = nco_sin(c, (phase + (uint32_t)c->table_size) & mask);
+    int32_t lim = (1 << (c->table_width - 1)) - 1; /* 2^14 fits 16 bits; clamp for narrower tables */
+    if (sn > lim) sn = lim;
+    if (cs > lim) cs = lim;
+    beats[i] = orc_pack_iq(cs, sn);
+  }
+  free(v);
+}

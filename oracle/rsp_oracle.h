@@ -139,6 +139,30 @@ typedef struct orc_rdcfg {
 void orc_rd_f32in(const float* in, size_t n_ch, const orc_rdcfg* c, double* thr, uint8_t* peak,
                   double* margin, double* mag_out /* may be NULL */, int n_threads);
 
+/* ---- PLFG -> NCO stimulus of the full chain (RspChain.scala:41-42,57-58) -------------------
+ * BUILD-DEFINED model (generators/plfg and generators/nco are empty submodules), anchored on
+ * FixedPLFGParams / FixedNCOParams (RspChain.scala:84-106), the tester's register program
+ * (RspChainVanillaTester.scala:80-94), its statement "peak is expected on frequency bin
+ * startingPoint * numOfPoints / (4 * tableSize)" (:85) and the float model calcExpectedNcoOut
+ * (RspChainTesterUtils.scala:174-181: amplitude 2^14, sample index 1..N, re = cos, im = sin).
+ *   PLFG: chirp i of the frame program = chirp type ordinal[i], repeated repeated[i] times; a chirp
+ *   type o is segment_nums[o] segments, RAM row o * max_segments + s; a segment word is
+ *   {length[31:24], slope[23:8], -, slope sign[1], reset-to-start[0]}; the value starts at
+ *   start_value at every chirp start, each sample outputs it and then adds +-slope.  The stream
+ *   repeats its program for as long as it is enabled (enable = 0: output 0).
+ *   NCO: phase accumulator of phase_width bits, incremented by the PLFG value BEFORE each output
+ *   (sample index starts at 1); quarter-wave table of table_size entries,
+ *   table[k] = floor(sin(2 pi k / 4 table_size) * 2^(table_width-2) + 1/2) (RoundHalfUp). */
+typedef struct orc_stim_cfg {
+  int32_t enable, start_value, num_chirps;
+  int32_t max_segments;
+  int32_t segment_nums[8], repeated[8], ordinal[8];
+  uint32_t ram[64];
+  int32_t table_size, table_width, phase_width;
+} orc_stim_cfg;
+void orc_plfg(const orc_stim_cfg* c, size_t n, int32_t* values);
+void orc_plfg_nco(const orc_stim_cfg* c, size_t n, uint32_t* beats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,24 @@ class ChainParamsC(C.Structure):
                 ("reserved", C.c_int32 * 8)]
 
 
+class PlfgParamsC(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("maxNumOfSegments", "maxNumOfDifferentChirps", "maxNumOfRepeatedChirps",
+                                         "maxChirpOrdinalNum", "maxNumOfFrames", "maxNumOfSamplesWidth",
+                                         "outputWidthInt", "outputWidthFrac")]
+
+
+class NcoParamsC(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("tableSize", "tableWidth", "phaseWidth", "rasterizedMode",
+                                         "nInterpolationTerms", "ditherEnable", "syncROMEnable", "phaseAccEnable",
+                                         "roundingMode", "pincType", "poffType")]
+
+
+class StimulusParamsC(C.Structure):
+    _fields_ = [("plfgParams", PlfgParamsC), ("ncoParams", NcoParamsC), ("plfgAddress", AddressSetC),
+                ("plfgRAM", AddressSetC), ("ncoAddress", AddressSetC), ("beatBytes", C.c_int32),
+                ("device", C.c_int32)]
+
+
 class Detection(C.Structure):
     _fields_ = [("frame", C.c_uint32), ("bin", C.c_uint32), ("doppler", C.c_uint32), ("word", C.c_uint32)]
 
@@ -86,6 +104,14 @@ SIGNATURES = {
     "rsp_device_free": (C.c_int, [C.c_int, C.c_void_p]),
     "rsp_memcpy_h2d": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rsp_memcpy_d2h": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rsp_stimulus_default_params": (None, [_P(StimulusParamsC)]),
+    "rsp_stimulus_create": (C.c_int, [_P(StimulusParamsC), _P(C.c_void_p)]),
+    "rsp_stimulus_destroy": (None, [C.c_void_p]),
+    "rsp_stimulus_write_reg": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "rsp_stimulus_read_reg": (C.c_int, [C.c_void_p, C.c_uint32, _P(C.c_uint32)]),
+    "rsp_stimulus_generate_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rsp_stimulus_generate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rsp_stimulus_last_error": (C.c_char_p, []),
     "rsp_pack_iq": (C.c_uint32, [C.c_int32, C.c_int32]),
     "rsp_unpack_word": (None, [C.c_uint32, C.c_int32, _P(C.c_int32), _P(C.c_uint32), _P(C.c_uint32)]),
     "rsp_unpack_word_f32": (None, [C.c_uint32, _P(C.c_float), _P(C.c_uint32)]),

@@ -391,6 +391,172 @@ class FftMagCfarChainVanilla:
         return ms.value
 
 
+# ----------------------------------------------------------------- the full chain: PLFG -> NCO -> FFT -> mag -> CFAR
+
+@dataclass
+class FixedPLFGParams:
+    """plfg.FixedPLFGParams, RspChain.scala:84-93"""
+    maxNumOfSegments: int = 4
+    maxNumOfDifferentChirps: int = 8
+    maxNumOfRepeatedChirps: int = 8
+    maxChirpOrdinalNum: int = 4
+    maxNumOfFrames: int = 4
+    maxNumOfSamplesWidth: int = 8
+    outputWidthInt: int = 16
+    outputWidthFrac: int = 0
+
+
+@dataclass
+class FixedNCOParams:
+    """nco.FixedNCOParams, RspChain.scala:94-106"""
+    tableSize: int = 128
+    tableWidth: int = 16
+    phaseWidth: int = 9
+    rasterizedMode: bool = False
+    nInterpolationTerms: int = 0
+    ditherEnable: bool = False
+    syncROMEnable: bool = False
+    phaseAccEnable: bool = True
+    roundingMode: str = "RoundHalfUp"
+    pincType: str = "Streaming"
+    poffType: str = "Fixed"
+
+
+@dataclass
+class RspChainVanillaParameters:
+    """rspChain.RspChainVanillaParameters, RspChain.scala:24-37"""
+    plfgParams: FixedPLFGParams
+    ncoParams: FixedNCOParams
+    fftParams: FFTParams
+    magParams: MAGParams
+    cfarParams: CFARParams
+    plfgAddress: AddressSet = AddressSet(0x30000000, 0xFF)
+    plfgRAM: AddressSet = AddressSet(0x30001000, 0xFFF)
+    ncoAddress: AddressSet = AddressSet(0x30000300, 0xF)
+    fftAddress: AddressSet = AddressSet(0x30000100, 0xFF)
+    magAddress: AddressSet = AddressSet(0x30000200, 0xFF)
+    cfarAddress: AddressSet = AddressSet(0x30002000, 0xFFF)
+    beatBytes: int = 4
+    device: int = 0
+
+
+def _check_s(rc: int):
+    if rc == N.RSP_OK:
+        return
+    msg = N.lib().rsp_stimulus_last_error().decode()
+    if rc == N.RSP_ERR_INVALID:
+        raise ValueError(f"requirement failed: {msg}")
+    if rc == N.RSP_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc == N.RSP_ERR_ADDRESS:
+        raise IndexError(msg)
+    raise RspError(msg)
+
+
+class RspChainVanilla:
+    """GPU stand-in for `LazyModule(new RspChainVanilla(params) with RspChainVanillaPins)`
+    (RspChain.scala:39-78): no stream input -- the PLFG/NCO pair generates the chain's beats on the
+    device; `ioMem` becomes memWriteWord, `outStream` becomes run()."""
+
+    def __init__(self, params: RspChainVanillaParameters):
+        self.params = params
+        lib = N.lib()
+        sp = N.StimulusParamsC()
+        for k in N.PlfgParamsC._fields_:
+            setattr(sp.plfgParams, k[0], int(getattr(params.plfgParams, k[0])))
+        n = params.ncoParams
+        for k in ("tableSize", "tableWidth", "phaseWidth", "nInterpolationTerms"):
+            setattr(sp.ncoParams, k, int(getattr(n, k)))
+        for k in ("rasterizedMode", "ditherEnable", "syncROMEnable", "phaseAccEnable"):
+            setattr(sp.ncoParams, k, int(bool(getattr(n, k))))
+        sp.ncoParams.roundingMode = 0 if n.roundingMode == "RoundHalfUp" else 1
+        sp.ncoParams.pincType = 0 if n.pincType == "Streaming" else 1
+        sp.ncoParams.poffType = 0 if n.poffType == "Fixed" else 1
+        for name in ("plfgAddress", "plfgRAM", "ncoAddress"):
+            a = getattr(params, name)
+            getattr(sp, name).base, getattr(sp, name).mask = a.base, a.mask
+        sp.beatBytes, sp.device = params.beatBytes, params.device
+        self._s = C.c_void_p()
+        _check_s(lib.rsp_stimulus_create(C.byref(sp), C.byref(self._s)))
+        self.chain = FftMagCfarChainVanilla(FftMagCfarVanillaParameters(
+            fftParams=params.fftParams, magParams=params.magParams, cfarParams=params.cfarParams,
+            fftAddress=params.fftAddress, magAddress=params.magAddress, cfarAddress=params.cfarAddress,
+            beatBytes=params.beatBytes, dtype=FIXED16, device=params.device))
+        self._lib = lib
+
+    def close(self):
+        if getattr(self, "_s", None):
+            self._lib.rsp_stimulus_destroy(self._s)
+            self._s = C.c_void_p()
+        if getattr(self, "chain", None) is not None:
+            self.chain.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def memWriteWord(self, addr: int, value: int):
+        """one AXI4 crossbar in front of all five blocks (RspChain.scala:48-54)"""
+        p = self.params
+        for a in (p.plfgAddress, p.plfgRAM, p.ncoAddress):
+            if (addr & ~a.mask & 0xFFFFFFFF) == a.base:
+                _check_s(self._lib.rsp_stimulus_write_reg(self._s, addr & 0xFFFFFFFF, int(value) & 0xFFFFFFFF))
+                return
+        self.chain.memWriteWord(addr, value)
+
+    def configure_plfg_tester(self, numFrames: int = 4, startValue: int = 16):
+        """the PLFG program of RspChainVanillaTester.scala:80-94, in its order"""
+        p, bb = self.params, self.params.beatBytes
+        seg = 6 * bb
+        rep = seg + 4 * bb
+        ordn = rep + 8 * bb
+        self.memWriteWord(p.plfgRAM.base, 0x24000000)                 # :86
+        self.memWriteWord(p.plfgAddress.base + 2 * bb, numFrames * 2)  # :87 number of frames
+        self.memWriteWord(p.plfgAddress.base + 4 * bb, 1)              # :88 number of chirps
+        self.memWriteWord(p.plfgAddress.base + 5 * bb, startValue)     # :89 start value
+        self.memWriteWord(p.plfgAddress.base + seg, 1)                 # :90 segments of the first chirp
+        self.memWriteWord(p.plfgAddress.base + rep, 1)                 # :91 repeated chirps
+        self.memWriteWord(p.plfgAddress.base + ordn, 0)                # :92
+        self.memWriteWord(p.plfgAddress.base + bb, 0)                  # :93 reset bit = 0
+        self.memWriteWord(p.plfgAddress.base, 1)                       # :94 enable
+
+    def configure(self, rt: "RunTimeRspChainParams"):
+        self.chain.configure(rt)   # RspChainVanillaTester.scala:96-146 == the stand-alone chain's sequence
+
+    def stimulus(self, n_samples: int) -> np.ndarray:
+        out = np.empty(n_samples, np.uint32)
+        _check_s(self._lib.rsp_stimulus_generate(self._s, out.ctypes.data_as(C.c_void_p), n_samples))
+        return out
+
+    def run(self, n_frames: int = 1) -> np.ndarray:
+        """collect n_frames x fftSize output words from outStream (RspChainVanillaTester.scala:157-163)"""
+        n = self.chain.fftSize
+        d_beats = DeviceBuffer(4 * n * n_frames, self.params.device)
+        d_out = DeviceBuffer(4 * n * n_frames, self.params.device)
+        try:
+            self.chain.synchronize()
+            _check_s(self._lib.rsp_stimulus_generate_device(self._s, C.c_void_p(d_beats.ptr), n * n_frames, None))
+            # generation ran on the null stream: make it visible to the chain's stream
+            import ctypes
+            N.lib().rsp_chain_synchronize(self.chain._h)
+            _sync_device(self.params.device)
+            self.chain.process_device(d_beats.ptr, n_frames, d_out.ptr)
+            self.chain.synchronize()
+            return d_out.download(np.uint32, n * n_frames).reshape(n_frames, n)
+        finally:
+            d_beats.free()
+            d_out.free()
+
+
+def _sync_device(device: int):
+    # a 4-byte D2H copy on the null stream orders everything queued on it before the host returns
+    b = DeviceBuffer(4, device)
+    b.download(np.uint32, 1)
+    b.free()
+
+
 # ----------------------------------------------------------------- word formats
 
 def unpack_output(words, fftSize: int):
