@@ -62,11 +62,15 @@ def main():
         raise SystemExit("bench.py needs an MI355X; no HIP device visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+    # RSP_BENCH_FORCE_DIST=1 runs the collective path with a 1-rank RCCL group (rehearsal on a 1-GPU box)
+    use_dist = world > 1 or bool(os.environ.get("RSP_BENCH_FORCE_DIST"))
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
 
     if args.workload != "cfg2":
-        return other_workload(args, torch, dist, R, rank, local_rank, world, dev)
+        return other_workload(args, torch, dist, R, rank, local_rank, world, dev, use_dist)
     n, frames = args.fft, args.chirps
     cells = n * frames
     params = R.FftMagCfarVanillaParameters(
@@ -76,8 +80,12 @@ def main():
                                  guardWindowSize=4, divSum=5, thresholdScaler=3.5)
     dut = R.FftMagCfarChainVanilla(params)
     dut.configure(rt)
-    main_stream = torch.cuda.current_stream()
+    # an explicit (non-default) stream: handle 0 would mean "the chain's own stream" to the C ABI, and
+    # the events below must be recorded on the stream the kernels really run on
+    main_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(main_stream)
     dut.set_stream(main_stream.cuda_stream)
+    assert main_stream.cuda_stream != 0
 
     # ---- synthetic chirp frames, generated on the device (3 point targets of
     # amplitude 0.4/0.2/0.1 at random range bins + complex white noise, sigma 0.05) ----
@@ -85,7 +93,8 @@ def main():
     g.manual_seed(1234 + rank)
     t = torch.arange(n, device=dev, dtype=torch.float32)
     ins, outs, lists, counts = [], [], [], []
-    cap = 1 << 16
+    cap = 1 << 15  # list capacity per rank and step (expected ~22 k peaks): 512 KiB, so that the 8-rank
+    # all-gather (4 MiB) stays well inside one step over xGMI
     for s in range(N_SETS):
         x = 0.05 * torch.randn(frames, n, 2, device=dev, generator=g)
         bins = torch.randint(0, n, (frames, 3), device=dev, generator=g).to(torch.float32)
@@ -95,32 +104,32 @@ def main():
             x[..., 1] += a * torch.sin(ph)
         ins.append(x.contiguous())
         outs.append(torch.empty(frames, n, dtype=torch.int32, device=dev))
-        lists.append(torch.empty(cap, 4, dtype=torch.int32, device=dev))
-        counts.append(torch.zeros(1, dtype=torch.int32, device=dev))
-    if world > 1:
-        from rsp_chains_amd.dist import gather_detections
+        packed = torch.zeros(cap + 1, 4, dtype=torch.int32, device=dev)  # row 0 = count, rows 1.. = list
+        lists.append(packed)
+        counts.append(packed[0, :1])
+    if use_dist:
+        from rsp_chains_amd.dist import gather_packed
         comm_stream = torch.cuda.Stream(device=dev)
-        g_lists = [torch.empty(world * cap, 4, dtype=torch.int32, device=dev) for _ in range(N_SETS)]
-        g_counts = [torch.empty(world, dtype=torch.int32, device=dev) for _ in range(N_SETS)]
+        g_lists = [torch.empty(world * (cap + 1), 4, dtype=torch.int32, device=dev) for _ in range(N_SETS)]
         ready = [torch.cuda.Event() for _ in range(N_SETS)]     # list of set s written
         gathered = [torch.cuda.Event() for _ in range(N_SETS)]  # list of set s gathered (reusable)
 
     def step(i):
         s = i % N_SETS
-        if world > 1 and i >= N_SETS:
+        if use_dist and i >= N_SETS:
             main_stream.wait_event(gathered[s])  # do not overwrite a list still being gathered
-        dut.process_detect_device(ins[s].data_ptr(), frames, outs[s].data_ptr(), lists[s].data_ptr(), cap,
+        dut.process_detect_device(ins[s].data_ptr(), frames, outs[s].data_ptr(), lists[s][1:].data_ptr(), cap,
                                   counts[s].data_ptr())
-        if world > 1:
+        if use_dist:
             ready[s].record(main_stream)
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(ready[s])
-                gather_detections(lists[s], counts[s], cap, out_list=g_lists[s], out_counts=g_counts[s])
+                gather_packed(lists[s], out=g_lists[s])
                 gathered[s].record(comm_stream)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -132,7 +141,7 @@ def main():
         step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -182,11 +191,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ins[0], n, frames)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
-def other_workload(args, torch, dist, R, rank, local_rank, world, dev):
+def other_workload(args, torch, dist, R, rank, local_rank, world, dev, use_dist):
     """cfg3: 8 Rx x 4096 x 512 2-D range-Doppler + 2-D CA-CFAR (28 B/cell algorithmic);
     cfg4: OS-CFAR (R = 32, k = 24, G = 4) on 8192-point spectra, 2048 chirps (12 B/cell)."""
     if args.workload in ("cfg3", "cfg5"):
@@ -213,7 +222,8 @@ def other_workload(args, torch, dist, R, rank, local_rank, world, dev):
         kernel = "chain1d_gos_kernel<13,f32>"
     dut = R.FftMagCfarChainVanilla(params)
     dut.configure(rt)
-    stream = torch.cuda.current_stream()
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     dut.set_stream(stream.cuda_stream)
     g = torch.Generator(device=dev)
     g.manual_seed(2345 + rank)
@@ -222,15 +232,14 @@ def other_workload(args, torch, dist, R, rank, local_rank, world, dev):
         x.view(-1, 2)[:: 65537, 0] += 20.0
     cells = int(np.prod(shape))
     outs = [torch.empty(cells, dtype=torch.int32, device=dev) for _ in range(N_SETS)]
-    cap = 1 << 16
-    lists = [torch.empty(cap, 4, dtype=torch.int32, device=dev) for _ in range(N_SETS)]
-    counts = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(N_SETS)]
-    gather = args.workload == "cfg5" and world > 1
+    cap = 1 << 15
+    lists = [torch.zeros(cap + 1, 4, dtype=torch.int32, device=dev) for _ in range(N_SETS)]  # row 0 = count
+    counts = [p[0, :1] for p in lists]
+    gather = args.workload == "cfg5" and use_dist
     if gather:
-        from rsp_chains_amd.dist import gather_detections
+        from rsp_chains_amd.dist import gather_packed
         comm = torch.cuda.Stream(device=dev)
-        g_lists = [torch.empty(world * cap, 4, dtype=torch.int32, device=dev) for _ in range(N_SETS)]
-        g_counts = [torch.empty(world, dtype=torch.int32, device=dev) for _ in range(N_SETS)]
+        g_lists = [torch.empty(world * (cap + 1), 4, dtype=torch.int32, device=dev) for _ in range(N_SETS)]
         ready = [torch.cuda.Event() for _ in range(N_SETS)]
         gathered = [torch.cuda.Event() for _ in range(N_SETS)]
 
@@ -240,17 +249,17 @@ def other_workload(args, torch, dist, R, rank, local_rank, world, dev):
             stream.wait_event(gathered[s])
         dut.process_device(ins[s].data_ptr(), units, outs[s].data_ptr())
         if args.workload == "cfg5":
-            dut.detections_device(outs[s].data_ptr(), units, lists[s].data_ptr(), cap, counts[s].data_ptr())
+            dut.detections_device(outs[s].data_ptr(), units, lists[s][1:].data_ptr(), cap, counts[s].data_ptr())
         if gather:
             ready[s].record(stream)
             with torch.cuda.stream(comm):
                 comm.wait_event(ready[s])
-                gather_detections(lists[s], counts[s], cap, out_list=g_lists[s], out_counts=g_counts[s])
+                gather_packed(lists[s], out=g_lists[s])
                 gathered[s].record(comm)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -262,7 +271,7 @@ def other_workload(args, torch, dist, R, rank, local_rank, world, dev):
         step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -282,7 +291,7 @@ def other_workload(args, torch, dist, R, rank, local_rank, world, dev):
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": bpc * cells}}), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

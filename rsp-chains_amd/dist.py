@@ -50,6 +50,27 @@ def gather_detections(local_list, local_count, cap: int, frame_offset: int = 0, 
     return lists, out_counts
 
 
+def gather_packed(packed, group=None, out=None, async_op: bool = False):
+    """ONE collective per step: `packed` is an int32 tensor [cap + 1, 4] whose row 0 carries the
+    detection count in column 0 and rows 1.. the list (point the C ABI's d_count at row 0 and d_list
+    at row 1).  Returns the gathered [world, cap + 1, 4] tensor (and the work handle with async_op)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rows = packed.shape[0]
+    if out is None:
+        out = torch.empty((world * rows, DET_WORDS), dtype=packed.dtype, device=packed.device)
+    h = dist.all_gather_into_tensor(out, packed, group=group, async_op=async_op)
+    view = out.view(world, rows, DET_WORDS)
+    return (view, h) if async_op else view
+
+
+def unpack_gathered(view):
+    """[world, cap + 1, 4] from gather_packed -> (lists [world, cap, 4], counts [world])"""
+    return view[:, 1:, :], view[:, 0, 0]
+
+
 def merge_gathered(lists, counts, frames_per_rank):
     """Host-side: concatenate the valid rows of every rank with global frame numbers.
     frames_per_rank[r] = first global frame of rank r."""

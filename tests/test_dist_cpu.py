@@ -17,7 +17,7 @@ WORKER = textwrap.dedent("""
     import torch, torch.distributed as dist
     sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
     import rsp_chains_amd as R
-    from rsp_chains_amd.dist import shard_range, gather_detections, merge_gathered
+    from rsp_chains_amd.dist import shard_range, gather_detections, gather_packed, unpack_gathered, merge_gathered
     from oracle import oracle as O
     from helpers import make_params, oracle_cfg, tone_beats
     dist.init_process_group("gloo")
@@ -40,6 +40,13 @@ WORKER = textwrap.dedent("""
     got = sorted(zip(merged[:, 0].tolist(), merged[:, 1].tolist()))
     assert got == want, (rank, got[:5], want[:5])
     assert int(counts.sum()) == len(want)
+    # the one-collective form bench.py uses: row 0 = count, rows 1.. = list
+    packed = torch.zeros((cap + 1, 4), dtype=torch.int32)
+    packed[0, 0] = k
+    packed[1:] = torch.from_numpy(lst)
+    l2, c2 = unpack_gathered(gather_packed(packed))
+    m2 = merge_gathered(l2, c2, firsts)
+    assert sorted(zip(m2[:, 0].tolist(), m2[:, 1].tolist())) == want
     dist.barrier(); dist.destroy_process_group()
     print("rank", rank, "ok", len(want))
 """)
