@@ -794,7 +794,8 @@ hipError_t launch_chain1d(const Chain1dLaunch& a0) {
   if (a0.n_frames == 0) return hipSuccess;
   // kernels address a launch's input with 32-bit byte offsets: split into < 4 GiB pieces
   const uint64_t beat = a0.fixed ? 4 : 8;
-  const uint32_t max_frames = (uint32_t)((0xFFFFFFFFull / (beat << a0.log2n)) & ~63ull);
+  uint32_t max_frames = (uint32_t)((0xFFFFFFFFull / (beat << a0.log2n)) & ~63ull);
+  if (const char* dbg = getenv("RSP_DEBUG_MAX_FRAMES")) max_frames = (uint32_t)atoi(dbg);  // tests only
   Chain1dLaunch a = a0;
   for (uint32_t done = 0; done < a0.n_frames; done += max_frames) {
     a.n_frames = a0.n_frames - done < max_frames ? a0.n_frames - done : max_frames;

@@ -302,3 +302,36 @@ def test_cash_register_only_exists_with_includeCASH(gpu):
         dut.memWriteWord(0x30002000 + 6 * 4, 3)          # cfarMode = CASH on a build without it
         with pytest.raises(ValueError):
             dut.check()
+
+
+def test_chunked_launch_path(gpu, monkeypatch):
+    """Launches whose input would exceed 4 GiB are split (kernels use 32-bit byte offsets).  Force the
+    split at 64 frames and check dense words and the fused detection list are unchanged."""
+    n, frames = 1024, 200
+    params = make_params(n)
+    rt = R.RunTimeRspChainParams()
+    beats = np.concatenate([tone_beats(8, n, 71), random_beats(frames - 8, n, 72)])
+    ref = O.chain_fixed(beats, oracle_cfg(params, rt)).reshape(frames, n)
+    monkeypatch.setenv("RSP_DEBUG_MAX_FRAMES", "64")
+    with R.FftMagCfarChainVanilla(params) as dut:
+        dut.configure(rt)
+        assert np.array_equal(dut.stream(beats), ref)
+        det, found = dut.detections(beats)
+    fr, bn = np.nonzero(ref & 1)
+    assert found == fr.size and np.array_equal(det["frame"], fr) and np.array_equal(det["bin"], bn)
+
+
+def test_two_chains_on_two_streams(gpu):
+    """Distinct handles are independent (one per host thread): interleaved use gives the same results."""
+    n = 512
+    pa, pb = make_params(n), make_params(n, dtype=R.F32)
+    rta = R.RunTimeRspChainParams(fftSize=n)
+    rtb = R.RunTimeRspChainParams(fftSize=n, CFARMode="Cell Averaging")
+    beats = random_beats(9, n, 5)
+    x = R.stimulus.chirp_frames(9, n, seed=6)
+    with R.FftMagCfarChainVanilla(pa) as a, R.FftMagCfarChainVanilla(pb) as b:
+        a.configure(rta); b.configure(rtb)
+        outs = [(a.stream(beats), b.stream(x)) for _ in range(3)]
+    for oa, ob in outs:
+        assert np.array_equal(oa, outs[0][0]) and np.array_equal(ob, outs[0][1])
+    assert np.array_equal(outs[0][0], O.chain_fixed(beats, oracle_cfg(pa, rta)).reshape(9, n))
