@@ -792,6 +792,7 @@ static hipError_t launch_m(const Chain1dLaunch& a) {
 
 hipError_t launch_chain1d(const Chain1dLaunch& a0) {
   if (a0.n_frames == 0) return hipSuccess;
+  if (a0.log2n < kMinLog2N) return launch_chain1d_small(a0);
   // kernels address a launch's input with 32-bit byte offsets: split into < 4 GiB pieces
   const uint64_t beat = a0.fixed ? 4 : 8;
   uint32_t max_frames = (uint32_t)((0xFFFFFFFFull / (beat << a0.log2n)) & ~63ull);

@@ -25,7 +25,8 @@ struct ChainRegs {
   int32_t lin_shl, lin_shr, log_shl, log_shr, log_scaler, tmax, tmin;
 };
 
-constexpr int kMinLog2N = 8;   // LDS scan rows are 16 lanes x 16 cells = 256 cells
+constexpr int kMinLog2N = 8;       // LDS-tiled kernels: scan rows are 16 lanes x 16 cells = 256 cells
+constexpr int kMinLog2NSmall = 4;  // one-thread-per-frame kernel (small.hip): 16..128 points
 constexpr int kMaxLog2N = 13;  // 8192 points: 68 KiB LDS per frame
 constexpr int kMaxRef = 128;   // refWindow + guardWindow <= 256 (LDS prefix halo)
 

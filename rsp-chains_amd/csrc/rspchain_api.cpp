@@ -113,9 +113,9 @@ int validate(const rsp_chain_params* p) {
     return fail(RSP_ERR_INVALID, "dtype %d", p->dtype);
   if (!is_pow2(f.numPoints)) return fail(RSP_ERR_INVALID, "numPoints = %d is not a power of two", f.numPoints);
   const int m_max = ilog2(f.numPoints);
-  if (m_max < rsp::kMinLog2N || m_max > rsp::kMaxLog2N)
+  if (m_max < rsp::kMinLog2NSmall || m_max > rsp::kMaxLog2N)
     return fail(RSP_ERR_UNSUPPORTED, "numPoints = %d: the GPU path holds %d..%d-point frames in LDS",
-                f.numPoints, 1 << rsp::kMinLog2N, 1 << rsp::kMaxLog2N);
+                f.numPoints, 1 << rsp::kMinLog2NSmall, 1 << rsp::kMaxLog2N);
   if (f.dataWidth != 16 || f.twiddleWidth != 16)
     return fail(RSP_ERR_UNSUPPORTED, "dataWidth/twiddleWidth = %d/%d: only the reference's 16/16 is implemented",
                 f.dataWidth, f.twiddleWidth);
@@ -197,7 +197,8 @@ int check_regs(const rsp_chain* c) {
   const int m = (int)c->fft_stages;
   if (m > m_max || m < 1) return fail(RSP_ERR_INVALID, "FFT stages = %d exceeds log2(numPoints) = %d", m, m_max);
   if (!p.fftParams.runTime && m != m_max) return fail(RSP_ERR_INVALID, "runTime = false but stages register = %d != %d", m, m_max);
-  if (m < rsp::kMinLog2N) return fail(RSP_ERR_UNSUPPORTED, "fftSize = %d: the GPU path needs >= %d points", 1 << m, 1 << rsp::kMinLog2N);
+  if (m < rsp::kMinLog2NSmall) return fail(RSP_ERR_UNSUPPORTED, "fftSize = %d: the GPU path needs >= %d points", 1 << m, 1 << rsp::kMinLog2NSmall);
+  if (m < rsp::kMinLog2N && p.dopplerPoints) return fail(RSP_ERR_UNSUPPORTED, "2-D chain: range FFT needs >= %d points", 1 << rsp::kMinLog2N);
   const int n = 1 << m;
   if ((int)c->cfar[kFftSize] != n)
     return fail(RSP_ERR_INVALID, "CFAR fftSize register = %u but FFT stages register selects %d points", c->cfar[kFftSize], n);
@@ -228,7 +229,7 @@ int check_regs(const rsp_chain* c) {
   }
   if (c->cfar[kAlgorithm] > 1) return fail(RSP_ERR_INVALID, "cfarAlgorithm register = %u", c->cfar[kAlgorithm]);
   if (uses_gos(c)) {
-    if (R < 4 || R > 64) return fail(RSP_ERR_UNSUPPORTED, "GOS CFAR: refWindowSize = %d, the GPU sorter is built for 4..64", R);
+    if (m >= rsp::kMinLog2N && (R < 4 || R > 64)) return fail(RSP_ERR_UNSUPPORTED, "GOS CFAR: refWindowSize = %d, the GPU sorter is built for 4..64", R);
     if (m == rsp::kMaxLog2N && c->cfar[kIndexLagg] != c->cfar[kIndexLead])
       return fail(RSP_ERR_UNSUPPORTED, "GOS CFAR at %d points needs indexLagg == indexLead (LDS)", n);
   }

@@ -335,3 +335,30 @@ def test_two_chains_on_two_streams(gpu):
     for oa, ob in outs:
         assert np.array_equal(oa, outs[0][0]) and np.array_equal(ob, outs[0][1])
     assert np.array_equal(outs[0][0], O.chain_fixed(beats, oracle_cfg(pa, rta)).reshape(9, n))
+
+
+@pytest.mark.parametrize("n", [16, 32, 64, 128])
+def test_small_runtime_fft_sizes(gpu, n):
+    """runTime = true: the stages register may select any 2^k <= numPoints (Tester:82).  Frames below
+    256 points run on the one-thread-per-frame kernel; FIXED16 bit-exact, F32 in tolerance, all modes."""
+    ref_w, guard = (2, 1) if n == 16 else (4, 2)
+    for mode, alg, kw in (("Greatest Of", R.CACFARType, {}), ("Cell Averaging", R.CACFARType, dict(peakGrouping=1)),
+                          ("Smallest Of", R.GOSCFARType, dict(indexLagg=1, indexLead=ref_w - 1, divSum=None)),
+                          ("CASH", R.CACFARType, dict(subWindowSize=ref_w // 2))):
+        params = make_params(1024, alg=alg, includeCASH=(mode == "CASH"), edge="wrap" if mode == "Cell Averaging" else "zero")
+        rt = R.RunTimeRspChainParams(fftSize=n, CFARMode=mode, refWindowSize=ref_w, guardWindowSize=guard,
+                                     **{"divSum": R.log2Up(ref_w), **kw})
+        beats = random_beats(70, n, 100 + n)       # 70 frames: more than one 64-frame workgroup
+        got = run_fixed(params, rt, beats)
+        assert np.array_equal(got, O.chain_fixed(beats, oracle_cfg(params, rt)).reshape(got.shape)), (n, mode)
+    paramsf = make_params(1024, dtype=R.F32)
+    rt = R.RunTimeRspChainParams(fftSize=n, CFARMode="Cell Averaging", refWindowSize=ref_w, guardWindowSize=guard,
+                                 divSum=R.log2Up(ref_w))
+    x = R.stimulus.chirp_frames(5, n, seed=n)
+    with R.FftMagCfarChainVanilla(paramsf) as dut:
+        dut.configure(rt)
+        words = dut.stream(x)
+        det, found = dut.detections(x)
+    thr, peak, margin, mag = O.chain_f32(x, oracle_fcfg(paramsf, rt), want_mag=True)
+    compare_f32(words, thr, peak, margin, mag, min_decided=0.8)
+    assert found == int((words & 1).sum())

@@ -25,7 +25,7 @@ def test_reference_parameter_sets_validate():
 
 @pytest.mark.parametrize("mutate,code", [
     (lambda p: setattr(p.fftParams, "numPoints", 1000), N.RSP_ERR_INVALID),
-    (lambda p: setattr(p.fftParams, "numPoints", 128), N.RSP_ERR_UNSUPPORTED),
+    (lambda p: (setattr(p.fftParams, "numPoints", 8), setattr(p.cfarParams, "fftSize", 8)), N.RSP_ERR_UNSUPPORTED),
     (lambda p: setattr(p.fftParams, "numPoints", 16384), N.RSP_ERR_UNSUPPORTED),
     (lambda p: setattr(p.fftParams, "dataWidth", 18), N.RSP_ERR_UNSUPPORTED),
     (lambda p: setattr(p.fftParams, "useBitReverse", False), N.RSP_ERR_UNSUPPORTED),
