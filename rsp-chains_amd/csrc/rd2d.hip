@@ -7,12 +7,15 @@
 //   range_fft_kernel   rows: FFT over r (contiguous), complex out in natural order  (8 R + 8 W)
 //   doppler_mag_kernel columns: FFT over d for 16 adjacent range bins per workgroup so that
 //                      every global access is a 128-B (in) / 64-B (out) segment; |.| out (8 R + 4 W)
-//   cfar2d_kernel      tile + halo in LDS, separable sliding box sums (outer - guard box),
-//                      threshold, word out                                           (4 R + 4 W)
+//   cfar2d_walk_kernel (windows of cfg 3 / 5, compile-time) one wave walks a 128-column strip down
+//                      the Doppler axis: register ring of rows, running column sums, DPP prefix +
+//                      ds_bpermute for the row sums; no LDS memory, no barriers       (4 R + 4 W)
+//   cfar2d_kernel      (any run-time windows) tile + halo in LDS, separable sliding box sums
 // = 36 B/cell against the 28 B/cell a fully fused Doppler+CFAR pass would need (the CFAR halo
 // crosses workgroup tiles in range; fusing it means recomputing halo columns' FFTs).
 #include <hip/hip_runtime.h>
 #include <float.h>
+#include <stdlib.h>
 
 #include "chain_regs.hpp"
 #include "fft_lds.hpp"
@@ -73,7 +76,13 @@ doppler_mag_kernel(const f32x2* __restrict__ in, float* __restrict__ mag, uint32
   // lanes run over the C adjacent range bins first: a wave touches 64 / C rows x (C x 8 B) segments
   const int tid = threadIdx.x, fl = tid % C, tau = tid / C;
   const uint32_t tiles_per_ch = nr / C;
-  const uint32_t ch = blockIdx.x / tiles_per_ch, r0 = (blockIdx.x % tiles_per_ch) * C;
+  // workgroups are dealt round-robin to the 8 XCDs: give each XCD a contiguous run of column tiles,
+  // so that the two
+  // 8-column tiles sharing a 128-B line meet in the same L2 (-25% at 1024 Doppler bins; with 16 columns a
+  // tile reads whole lines and the plain order is the faster one)
+  const uint32_t tile = (C * 8 < 128 && gridDim.x % 8 == 0) ? (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8
+                                                            : blockIdx.x;
+  const uint32_t ch = tile / tiles_per_ch, r0 = (tile % tiles_per_ch) * C;
   f32x2* buf = reinterpret_cast<f32x2*>(smem + (size_t)fl * kColBytes(MD));
   const size_t col = (size_t)ch * ND * nr + r0 + fl;  // element index of (ch, d = 0, r)
   const f32x2* src = in + col + (size_t)first_sample<MD>(tau) * nr;
@@ -194,6 +203,111 @@ cfar2d_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_
   }
 }
 
+// ---------------------------------------------------------------- 2-D CA-CFAR, compile-time windows
+// One WAVE walks a 128-column strip (2 adjacent range bins per lane, 8-byte loads and stores) down
+// kWalkSeg Doppler rows.  The last 2 HD + 2 map rows live in a register ring (fully unrolled, so
+// ring indices are compile-time); the ring's spare slots are rows already in flight from HBM.
+//   vertical:   Vo / Vi = sums over the 2 HD + 1 / 2 GD + 1 rows around the output row, updated by
+//               one add and one subtract per row (registers only);
+//   horizontal: wave-wide inclusive prefix of Vo (Vi) by DPP, window sum = prefix[c + H] -
+//               prefix[c - H - 1] fetched with ds_bpermute (no LDS memory, no barriers).
+// Lanes LB .. LE own complete windows: 2 (LE - LB + 1) output columns per strip.
+template <int CTRL, int ROWMASK, bool BOUND>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, BOUND));
+}
+__device__ __forceinline__ float wave_scan_f(float v) {
+  v += dpp_f<0x111, 0xf, true>(v);   // row_shr:1,2,4,8: inclusive scan of each 16-lane row
+  v += dpp_f<0x112, 0xf, true>(v);
+  v += dpp_f<0x114, 0xf, true>(v);
+  v += dpp_f<0x118, 0xf, true>(v);
+  v += dpp_f<0x142, 0xa, false>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_f<0x143, 0xc, false>(v);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+// inclusive column prefix at column (2 lane + T) of the strip; p0 / p1 = prefix at this lane's columns
+template <int T>
+__device__ __forceinline__ float prefix_at(float p0, float p1, int lane) {
+  constexpr int SH = (T >= 0) ? T / 2 : -((1 - T) / 2), PAR = T - 2 * SH;
+  static_assert(PAR == 0 || PAR == 1, "floor division");
+  const int r = __builtin_amdgcn_ds_bpermute(((lane + SH) & 63) << 2, __builtin_bit_cast(int, PAR ? p1 : p0));
+  return __builtin_bit_cast(float, r);
+}
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+constexpr int kWalkRing = 32;
+constexpr int walk_lb(int hr) { return (hr + 2) / 2; }
+constexpr int walk_le(int hr) { return (126 - hr) / 2; }
+constexpr int walk_outw(int hr) { return 2 * (walk_le(hr) - walk_lb(hr) + 1); }
+
+template <int RR, int GR, int RD, int GD, int SEG>
+__global__ void __launch_bounds__(256)
+cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_t nd, uint32_t nr,
+                   uint32_t strips, int edge, float kA, float kB) {
+  constexpr int HR = RR + GR, HD = RD + GD, SPAN = 2 * HD + 2, RING = kWalkRing;
+  constexpr int LB = walk_lb(HR), LE = walk_le(HR), OUTW = walk_outw(HR);
+  static_assert(SPAN < RING && SEG % RING == 0, "ring holds the taps plus at least one row in flight");
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t seg_groups = nd / SEG / 4;
+  // contiguous run of strips per XCD: neighbouring strips share halo columns and rows through one L2
+  const uint32_t blk = (gridDim.x % 8 == 0) ? (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : blockIdx.x;
+  const uint32_t sg = blk % seg_groups, strip = (blk / seg_groups) % strips;
+  const uint32_t ch = blk / (seg_groups * strips);
+  const int d0 = (int)(sg * 4 + w) * SEG;
+  const int col = (int)(strip * OUTW) - 2 * LB + 2 * lane;  // even: both columns in or both out of the map
+  // buffer addressing: row offset in an SGPR, lane offset constant; a lane outside the map (zero edge)
+  // or without a complete window gets an out-of-range offset: its loads return 0, its stores are dropped
+  constexpr uint32_t kOob = 0xfffffff0u, kRsrc3 = 0x00020000u;
+  const uint32_t map_bytes = nd * nr * 4u;
+  const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(mag) + (size_t)ch * nd * nr, 0, (int)map_bytes, (int)kRsrc3);
+  const __amdgpu_buffer_rsrc_t rsrc_out =
+      __builtin_amdgcn_make_buffer_rsrc(out + (size_t)ch * nd * nr, 0, (int)map_bytes, (int)kRsrc3);
+  const bool readable = edge || (col >= 0 && col < (int)nr);
+  const bool owner = lane >= LB && lane <= LE && col < (int)nr;
+  const uint32_t voff_in = readable ? (uint32_t)(col & ((int)nr - 1)) * 4u : kOob;
+  const uint32_t voff_out = owner ? (uint32_t)col * 4u : kOob;
+  const float count = (float)((2 * HR + 1) * (2 * HD + 1) - (2 * GR + 1) * (2 * GD + 1));
+  const float kAc = kA / count;
+  // stream row p <-> map row d0 - HD + p (Doppler cyclic)
+  auto load_row = [&](int p) -> f32x2 {
+    const uint32_t d = (uint32_t)((d0 - HD + p) & ((int)nd - 1));
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_in, voff_in, d * nr * 4u, 0));
+  };
+  f32x2 ring[RING];
+#pragma unroll
+  for (int p = 0; p < RING - 1; ++p) ring[p] = load_row(p);
+  f32x2 vo = ring[0], vi = ring[HD - GD];
+#pragma unroll
+  for (int p = 1; p <= 2 * HD; ++p) vo += ring[p];
+#pragma unroll
+  for (int p = HD - GD + 1; p <= HD + GD; ++p) vi += ring[p];
+  for (int chunk = 0; chunk < SEG / RING; ++chunk) {
+#pragma unroll
+    for (int u = 0; u < RING; ++u) {
+      const int i = chunk * RING + u;
+      ring[(u + RING - 1) % RING] = load_row(i + RING - 1);
+      const float po1 = wave_scan_f(vo.x + vo.y), po0 = po1 - vo.y;
+      const float pi1 = wave_scan_f(vi.x + vi.y), pi0 = pi1 - vi.y;
+      const f32x2 so = {prefix_at<HR>(po0, po1, lane) - prefix_at<-HR - 1>(po0, po1, lane),
+                        prefix_at<1 + HR>(po0, po1, lane) - prefix_at<-HR>(po0, po1, lane)};
+      const f32x2 si = {prefix_at<GR>(pi0, pi1, lane) - prefix_at<-GR - 1>(pi0, pi1, lane),
+                        prefix_at<1 + GR>(pi0, pi1, lane) - prefix_at<-GR>(pi0, pi1, lane)};
+      const f32x2 cut = ring[(u + HD) % RING];
+      const float t0 = __fmaf_rn(so.x - si.x, kAc, kB), t1 = __fmaf_rn(so.y - si.y, kAc, kB);
+      u32x2 wd;
+      wd.x = (__float_as_uint(t0) & ~1u) | (uint32_t)(cut.x > t0);
+      wd.y = (__float_as_uint(t1) & ~1u) | (uint32_t)(cut.y > t1);
+      __builtin_amdgcn_raw_buffer_store_b64(wd, rsrc_out, voff_out, (uint32_t)(d0 + i) * nr * 4u, 0);
+      vo += ring[(u + SPAN - 1) % RING] - ring[u];
+      vi += ring[(u + HD + GD + 1) % RING] - ring[(u + HD - GD) % RING];
+      // keep every row's load at the top of its own step: the scheduler would otherwise sink the
+      // loads next to their first use, 10 rows later, and drain the prefetch pipeline
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- launchers
 
 template <int M>
@@ -257,7 +371,15 @@ hipError_t launch_rd2d(const Rd2dLaunch& a) {
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const float kA = a.regs.linear ? a.regs.scaler_f : 1.0f, kB = a.regs.linear ? 0.0f : a.regs.scaler_f;
   const bool spec = a.regs.R == 8 && a.regs.G == 2 && a.ref_d == 8 && a.guard_d == 2;  // cfg 3 / cfg 5
-  auto k = spec ? cfar2d_kernel<8, 2, 8, 2> : cfar2d_kernel<-1, -1, -1, -1>;
+  if (spec && !getenv("RSP_DEBUG_NO_WALK")) {
+    const uint32_t strips = (nr + walk_outw(10) - 1) / walk_outw(10);
+    // 64 rows per wave: 32 and 128 measure the same (the kernel is bound by its HBM stream)
+    constexpr uint32_t SEG = 64;
+    hipLaunchKernelGGL((cfar2d_walk_kernel<8, 2, 8, 2, SEG>), dim3(a.n_ch * strips * (nd / SEG / 4)), dim3(256), 0,
+                       a.stream, a.scratch_mag, a.out, nd, nr, strips, a.regs.edge, kA, kB);
+    return hipGetLastError();
+  }
+  auto k = cfar2d_kernel<-1, -1, -1, -1>;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3(a.n_ch * (nr / kTR) * (nd / kTD)), dim3(256), lds, a.stream, a.scratch_mag, a.out,

@@ -33,7 +33,7 @@ def targets(n_ch, nd, nr, seed, k=4, sigma=0.05):
 
 
 @pytest.mark.parametrize("nr,nd,edge", [(256, 256, "zero"), (1024, 512, "zero"), (512, 256, "wrap"), (4096, 512, "zero"),
-                                        (2048, 1024, "zero")])
+                                        (2048, 1024, "zero"), (4096, 256, "wrap"), (8192, 256, "zero")])
 def test_rd2d_against_oracle(gpu, nr, nd, edge):
     n_ch = 2
     params = rd_params(nr, nd, edge=edge)
@@ -51,6 +51,46 @@ def test_rd2d_against_oracle(gpu, nr, nd, edge):
                 mag.reshape(n_ch, -1))
     for ch, db, rb in where:           # every injected target is detected at its (Doppler, range) cell
         assert words[ch, db, rb] & 1
+
+
+@pytest.mark.parametrize("rr,gr,rd,gd,edge", [(4, 1, 5, 3, "zero"), (16, 3, 4, 1, "wrap"), (8, 2, 8, 1, "zero")])
+def test_rd2d_run_time_windows(gpu, rr, gr, rd, gd, edge):
+    """Windows other than the compile-time (8, 2, 8, 2) of cfg 3 / 5 take the tiled LDS kernel."""
+    nr, nd, n_ch = 512, 256, 2
+    params = rd_params(nr, nd, ref=rd, guard=gd, edge=edge)
+    rt = R.RunTimeRspChainParams(fftSize=nr, CFARMode="Cell Averaging", refWindowSize=rr, guardWindowSize=gr, divSum=4,
+                                 thresholdScaler=4.0)
+    x, where = targets(n_ch, nd, nr, seed=99 + rr)
+    with R.FftMagCfarChainVanilla(params) as dut:
+        dut.configure(rt)
+        words = dut.stream(x)
+    cfg = O.OrcRdCfg(log2nr=R.log2Up(nr), log2nd=R.log2Up(nd), mag_mode=O.MAG_JPL, scaler=4.0, ref_r=rr, ref_d=rd,
+                     guard_r=gr, guard_d=gd, edge=1 if edge == "wrap" else 0)
+    thr, peak, margin, mag = O.rd_f32(x, cfg, want_mag=True)
+    compare_f32(words.reshape(n_ch, -1), thr.reshape(n_ch, -1), peak.reshape(n_ch, -1), margin.reshape(n_ch, -1),
+                mag.reshape(n_ch, -1))
+
+
+@pytest.mark.parametrize("edge", ["zero", "wrap"])
+def test_rd2d_walker_agrees_with_tiled_kernel(gpu, edge, monkeypatch):
+    """The register-ring strip walker (compile-time windows) and the tiled LDS kernel are two
+    summation orders of the same statistic: thresholds agree to a few ulp, peaks wherever decided."""
+    nr, nd, n_ch = 1024, 256, 2
+    params = rd_params(nr, nd, edge=edge)
+    rt = R.RunTimeRspChainParams(fftSize=nr, CFARMode="Cell Averaging", refWindowSize=8, guardWindowSize=2, divSum=4,
+                                 thresholdScaler=4.0)
+    x, _ = targets(n_ch, nd, nr, seed=4242)
+    outs = []
+    for no_walk in (False, True):
+        if no_walk:
+            monkeypatch.setenv("RSP_DEBUG_NO_WALK", "1")
+        with R.FftMagCfarChainVanilla(params) as dut:
+            dut.configure(rt)
+            outs.append(dut.stream(x))
+    ta, pa = R.unpack_output_f32(outs[0])
+    tb, pb = R.unpack_output_f32(outs[1])
+    np.testing.assert_allclose(ta, tb, rtol=4e-6)
+    assert np.mean(pa != pb) < 1e-4
 
 
 def test_rd2d_detection_list(gpu):

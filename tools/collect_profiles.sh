@@ -13,4 +13,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_IN
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_$tag -- python3 $R/tools/prof_chain.py 4096 4096 8 > $O/pmc_$tag.log 2>&1
 done
 python3 $R/tools/pcie_rate.py > $O/pcie.json 2> $O/pcie.err
+for w in cfg3 cfg4 cfg5; do python3 $R/bench.py --workload $w --steps 20 --warmup 4 > $O/bench_$w.json 2> $O/bench_$w.err; done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfg3 -- python3 $R/bench.py --workload cfg3 --steps 20 --warmup 4 > /dev/null 2> $O/stats_cfg3.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfg4 -- python3 $R/bench.py --workload cfg4 --steps 20 --warmup 4 > /dev/null 2> $O/stats_cfg4.err
 echo done

@@ -30,6 +30,15 @@ json.dump({"chain1d_hbm_bytes_per_launch": traffic, "fetch_size_raw_kb": fetch_k
            "algorithmic_bytes_per_launch": 12 * 4096 * 4096, "pmc": pmc,
            "workload": "chain1d_kernel<12,f32>, 4096 chirps x 4096 points, tools/prof_chain.py"},
           open(os.path.join(dst, "traffic_r01.json"), "w"), indent=1)
+for w in ("cfg3", "cfg4", "cfg5"):
+    f = os.path.join(src, f"bench_{w}.json")
+    if os.path.exists(f) and os.path.getsize(f):
+        shutil.copy(f, os.path.join(dst, f"bench_r01_{w}.json"))
+for w in ("cfg3", "cfg4"):
+    for f in glob.glob(os.path.join(src, f"stats_{w}", "*", "*kernel_stats.csv")):
+        rows = list(csv.reader(open(f)))
+        keep = [rows[0]] + [r for r in rows[1:] if r and "rsp::" in r[0]]
+        csv.writer(open(os.path.join(dst, f"rocprof_r01_{w}_kernel_stats.csv"), "w")).writerows(keep)
 if os.path.exists(os.path.join(src, "pcie.json")):
     shutil.copy(os.path.join(src, "pcie.json"), os.path.join(dst, "pcie_inclusive_r01.json"))
 print(open(os.path.join(dst, "bench_r01.json")).read()[:600]); print("traffic", traffic)
