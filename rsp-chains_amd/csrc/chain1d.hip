@@ -806,6 +806,11 @@ hipError_t launch_chain1d(const Chain1dLaunch& a0) {
     a.frame_det = a0.frame_det ? a0.frame_det + (uint64_t)done * kFrameDetCap : nullptr;
     if (done) a.zero_a = a.zero_b = nullptr;
     hipError_t e;
+    if (chain1d_wave_supports(a)) {  // opt-in alternative formulation (chain1d_wave.hip)
+      e = launch_chain1d_wave(a);
+      if (e != hipSuccess) return e;
+      continue;
+    }
     switch (a.log2n) {
       case 8: e = launch_m<8>(a); break;
       case 9: e = launch_m<9>(a); break;

@@ -1,0 +1,83 @@
+"""chain1d_wave_kernel (csrc/chain1d_wave.hip): the one-wave-per-frame formulation of the F32
+4096-point chain, opt-in with RSP_CHAIN_WAVE=1 (the workgroup-per-frame kernel is the default and
+currently the faster one).  Same oracle, same tolerances; the two kernels are also compared with
+each other on the same input."""
+import numpy as np
+import pytest
+
+import rsp_chains_amd as R
+from oracle import oracle as O
+from helpers import make_params, oracle_fcfg, compare_f32
+
+pytestmark = pytest.mark.gpu
+N = 4096
+
+
+def run(params, rt, x, monkeypatch, wave, detect=False):
+    monkeypatch.setenv("RSP_CHAIN_WAVE", "1" if wave else "0")
+    with R.FftMagCfarChainVanilla(params) as dut:
+        dut.configure(rt)
+        if detect:
+            return dut.detections(x)
+        return dut.stream(x)
+
+
+@pytest.mark.parametrize("mode", ["Cell Averaging", "Greatest Of", "Smallest Of"])
+@pytest.mark.parametrize("edge", ["zero", "wrap"])
+@pytest.mark.parametrize("mag,grouping", [(2, 0), (2, 1), (0, 1), (1, 0)])
+def test_wave_kernel_against_oracle(gpu, monkeypatch, mode, edge, mag, grouping):
+    params = make_params(N, dtype=R.F32, edge=edge, leadLagg=64)
+    rt = R.RunTimeRspChainParams(fftSize=N, CFARMode=mode, magMode=mag, refWindowSize=32, divSum=5,
+                                 guardWindowSize=4, peakGrouping=grouping, logOrLinearMode=0 if mag == 1 else 1,
+                                 thresholdScaler=2.0 if mag == 1 else 3.5)
+    x = R.stimulus.chirp_frames(7, N, seed=4000 + mag)      # 7 frames: ragged against the 4-wave workgroup
+    words = run(params, rt, x, monkeypatch, wave=True)
+    thr, peak, margin, magr = O.chain_f32(x, oracle_fcfg(params, rt), want_mag=True)
+    compare_f32(words, thr, peak, margin, magr, atol=2.0 ** -9 if mag == 1 else 0.0)
+
+
+@pytest.mark.parametrize("ref,guard", [(2, 1), (16, 7), (32, 31)])
+def test_wave_kernel_window_geometry(gpu, monkeypatch, ref, guard):
+    """Smallest window, and the largest one that still fits one 64-cell block either side
+    (refWindow + guardWindow + 1 = 64)."""
+    params = make_params(N, dtype=R.F32, leadLagg=64, guard=32)
+    rt = R.RunTimeRspChainParams(fftSize=N, CFARMode="Greatest Of", refWindowSize=ref, guardWindowSize=guard,
+                                 divSum=int(np.log2(ref)), peakGrouping=1)
+    x = R.stimulus.chirp_frames(5, N, seed=77 + ref)
+    words = run(params, rt, x, monkeypatch, wave=True)
+    thr, peak, margin, magr = O.chain_f32(x, oracle_fcfg(params, rt), want_mag=True)
+    compare_f32(words, thr, peak, margin, magr, rtol=5e-5 if ref < 8 else 2e-5)
+
+
+def test_wave_and_workgroup_kernels_agree(gpu, monkeypatch):
+    """Two summation orders of the same statistic: thresholds within a few ulp, same peaks wherever
+    the decision is not within rounding; the detection lists name the same cells."""
+    params = make_params(N, dtype=R.F32)
+    rt = R.RunTimeRspChainParams(fftSize=N, CFARMode="Cell Averaging")
+    x = R.stimulus.chirp_frames(33, N, seed=5)
+    a = run(params, rt, x, monkeypatch, wave=True)
+    b = run(params, rt, x, monkeypatch, wave=False)
+    ta, pa = R.unpack_output_f32(a)
+    tb, pb = R.unpack_output_f32(b)
+    np.testing.assert_allclose(ta, tb, rtol=4e-6)
+    assert np.mean(pa != pb) < 1e-5
+    la, found = run(params, rt, x, monkeypatch, wave=True, detect=True)
+    fr, bins = np.nonzero(a & 1)
+    assert found == len(fr)
+    assert sorted(zip(la["frame"].tolist(), la["bin"].tolist())) == sorted(zip(fr.tolist(), bins.tolist()))
+    assert np.array_equal(la["word"], a[la["frame"], la["bin"]])
+
+
+def test_wave_kernel_large_batch(gpu, monkeypatch):
+    """A batch larger than the persistent grid (1024 waves): every wave loops over several frames,
+    the last ones over fewer; identical frames must give identical rows."""
+    params = make_params(N, dtype=R.F32)
+    rt = R.RunTimeRspChainParams(fftSize=N, CFARMode="Cell Averaging")
+    x = np.tile(R.stimulus.chirp_frames(8, N, seed=6), (331, 1))      # 2648 frames = 2.6 x the grid
+    big = run(params, rt, x, monkeypatch, wave=True)
+    small = run(params, rt, x[:8], monkeypatch, wave=False)
+    ref_t, ref_p = R.unpack_output_f32(small)
+    for k in (0, 1024 // 8, 330):
+        t, p = R.unpack_output_f32(big[8 * k:8 * k + 8])
+        np.testing.assert_allclose(t, ref_t, rtol=4e-6)
+    assert np.array_equal(big[:8], big[2640:])
