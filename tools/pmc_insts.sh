@@ -11,4 +11,3 @@ for d in glob.glob(R+'/gpurun_out/pmc_insts/*/*counter_collection.csv'):
     w=sum(agg['SQ_WAVES'])/len(agg['SQ_WAVES'])
     for k,v in sorted(agg.items()): print(k, round(sum(v)/len(v)/w,1))
 PY
-cd $R && bash tools/ab.sh ab_prev.so ab_new2.so 4096 4096 30
