@@ -10,8 +10,8 @@ CA-CFAR (R = 32, G = 4), 4096-chirp batch, fp32 -- 16 777 216 cells per step per
 A step = one pass of the fused chain kernel over one batch already resident in HBM,
 plus the compaction of its peak cells into a detection list.  Multi-GPU: chirps shard
 embarrassingly (weak scaling: every rank owns a full batch); the only collective is
-the RCCL all-gather of the detection lists, issued on a side stream so that it
-overlaps the next step's kernel.
+the RCCL all-gather of the detection lists: the lists of 4 consecutive steps share
+one block, one all-gather per block on a side stream under the following steps.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (chain1d):
 algorithmic bytes (12 B/cell: 8 in + 4 out) / its mean launch duration,
@@ -92,9 +92,8 @@ def main():
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
     t = torch.arange(n, device=dev, dtype=torch.float32)
-    ins, outs, lists, counts = [], [], [], []
-    cap = 1 << 15  # list capacity per rank and step (expected ~22 k peaks): 512 KiB, so that the 8-rank
-    # all-gather (4 MiB) stays well inside one step over xGMI
+    ins, outs = [], []
+    cap = 1 << 15  # list capacity per rank and step (expected ~22 k peaks): 512 KiB
     for s in range(N_SETS):
         x = 0.05 * torch.randn(frames, n, 2, device=dev, generator=g)
         bins = torch.randint(0, n, (frames, 3), device=dev, generator=g).to(torch.float32)
@@ -104,28 +103,46 @@ def main():
             x[..., 1] += a * torch.sin(ph)
         ins.append(x.contiguous())
         outs.append(torch.empty(frames, n, dtype=torch.int32, device=dev))
-        packed = torch.zeros(cap + 1, 4, dtype=torch.int32, device=dev)  # row 0 = count, rows 1.. = list
-        lists.append(packed)
-        counts.append(packed[0, :1])
+    # detection lists: packed [cap + 1, 4] per step (row 0 = count, rows 1.. = list).  G consecutive steps
+    # share one contiguous block so that ONE all-gather moves G lists (the collective's host-side cost,
+    # tens of microseconds, is of the order of a whole step); two blocks alternate, the gather of one
+    # runs on a side stream under the steps that fill the other.
+    G = N_SETS
+    rows = cap + 1
+    blocks = [torch.zeros(G * rows, 4, dtype=torch.int32, device=dev) for _ in range(2)]
+    lists = [[blocks[b][k * rows:(k + 1) * rows] for k in range(G)] for b in range(2)]
     if use_dist:
         from rsp_chains_amd.dist import gather_packed
         comm_stream = torch.cuda.Stream(device=dev)
-        g_lists = [torch.empty(world * (cap + 1), 4, dtype=torch.int32, device=dev) for _ in range(N_SETS)]
-        ready = [torch.cuda.Event() for _ in range(N_SETS)]     # list of set s written
-        gathered = [torch.cuda.Event() for _ in range(N_SETS)]  # list of set s gathered (reusable)
+        g_blocks = [torch.empty(world * G * rows, 4, dtype=torch.int32, device=dev) for _ in range(2)]
+        ready = [torch.cuda.Event() for _ in range(2)]     # block b written
+        gathered = [torch.cuda.Event() for _ in range(2)]  # block b gathered (reusable)
+
+    def gather_block(b):
+        ready[b].record(main_stream)
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(ready[b])
+            gather_packed(blocks[b], out=g_blocks[b])
+            gathered[b].record(comm_stream)
+
+    last = {"b": 0, "k": 0, "open": False}
 
     def step(i):
         s = i % N_SETS
-        if use_dist and i >= N_SETS:
-            main_stream.wait_event(gathered[s])  # do not overwrite a list still being gathered
-        dut.process_detect_device(ins[s].data_ptr(), frames, outs[s].data_ptr(), lists[s][1:].data_ptr(), cap,
-                                  counts[s].data_ptr())
-        if use_dist:
-            ready[s].record(main_stream)
-            with torch.cuda.stream(comm_stream):
-                comm_stream.wait_event(ready[s])
-                gather_packed(lists[s], out=g_lists[s])
-                gathered[s].record(comm_stream)
+        b, k = divmod(i % (2 * G), G)
+        if use_dist and k == 0 and i >= 2 * G:
+            main_stream.wait_event(gathered[b])  # do not overwrite a block still being gathered
+        lst = lists[b][k]
+        dut.process_detect_device(ins[s].data_ptr(), frames, outs[s].data_ptr(), lst[1:].data_ptr(), cap,
+                                  lst[0, :1].data_ptr())
+        last.update(b=b, k=k, open=k != G - 1)
+        if use_dist and k == G - 1:
+            gather_block(b)
+
+    def flush():  # a run that stops inside a block still gathers it
+        if use_dist and last["open"]:
+            gather_block(last["b"])
+            last["open"] = False
 
     def fence():
         torch.cuda.synchronize()
@@ -135,10 +152,12 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    flush()
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    flush()
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -152,12 +171,13 @@ def main():
     dut.profile_enable(True)
     for i in range(args.steps):
         step(args.warmup + args.steps + i)
+    flush()
     fence()
     tot_ms, launches = dut.profile_read()
     dut.profile_enable(False)
     kernel_ms = tot_ms / max(launches, 1)
 
-    n_det = int(counts[(args.warmup + args.steps - 1) % N_SETS].item())
+    n_det = int(lists[last["b"]][last["k"]][0, 0].item())
 
     if rank == 0:
         bytes_per_launch = 12.0 * cells
@@ -181,7 +201,7 @@ def main():
                                    f"{frames}-chirp batch per GPU, fp32, dense words + detection list",
                        "cells_per_step_per_gpu": cells, "buffer_sets": N_SETS,
                        "detections_last_step": n_det,
-                       "sharding": "chirps/channels per rank; RCCL all-gather of detection lists only"},
+                       "sharding": "chirps/channels per rank; one RCCL all-gather per 4 steps moves their 4 detection lists (side stream)"},
             "roofline": {"bound": "hbm", "kernel": "chain1d_kernel<12,f32>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -265,10 +285,12 @@ def other_workload(args, torch, dist, R, rank, local_rank, world, dev, use_dist)
 
     for i in range(args.warmup):
         step(i)
+    flush()
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    flush()
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
