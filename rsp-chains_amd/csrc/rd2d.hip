@@ -76,10 +76,9 @@ doppler_mag_kernel(const f32x2* __restrict__ in, float* __restrict__ mag, uint32
   // lanes run over the C adjacent range bins first: a wave touches 64 / C rows x (C x 8 B) segments
   const int tid = threadIdx.x, fl = tid % C, tau = tid / C;
   const uint32_t tiles_per_ch = nr / C;
-  // workgroups are dealt round-robin to the 8 XCDs: give each XCD a contiguous run of column tiles,
-  // so that the two
-  // 8-column tiles sharing a 128-B line meet in the same L2 (-25% at 1024 Doppler bins; with 16 columns a
-  // tile reads whole lines and the plain order is the faster one)
+  // workgroups are dealt round-robin to the 8 XCDs: give each XCD a contiguous run of column tiles, so
+  // that the two 8-column tiles sharing a 128-B line meet in the same L2 (-25 % at 1024 Doppler bins;
+  // with 16 columns a tile reads whole lines and the plain order is the faster one)
   const uint32_t tile = (C * 8 < 128 && gridDim.x % 8 == 0) ? (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8
                                                             : blockIdx.x;
   const uint32_t ch = tile / tiles_per_ch, r0 = (tile % tiles_per_ch) * C;
@@ -373,7 +372,7 @@ hipError_t launch_rd2d(const Rd2dLaunch& a) {
   const bool spec = a.regs.R == 8 && a.regs.G == 2 && a.ref_d == 8 && a.guard_d == 2;  // cfg 3 / cfg 5
   if (spec && !getenv("RSP_DEBUG_NO_WALK")) {
     const uint32_t strips = (nr + walk_outw(10) - 1) / walk_outw(10);
-    // 64 rows per wave: 32 and 128 measure the same (the kernel is bound by its HBM stream)
+    // 64 rows per wave: 32 measures the same, 128 is 6 % slower (fewer waves to hide the row latency)
     constexpr uint32_t SEG = 64;
     hipLaunchKernelGGL((cfar2d_walk_kernel<8, 2, 8, 2, SEG>), dim3(a.n_ch * strips * (nd / SEG / 4)), dim3(256), 0,
                        a.stream, a.scratch_mag, a.out, nd, nr, strips, a.regs.edge, kA, kB);
