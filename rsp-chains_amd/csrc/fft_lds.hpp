@@ -101,26 +101,52 @@ __device__ __forceinline__ f32x2 cmul(f32x2 a, f32x2 w) {
   return __builtin_elementwise_fma(ayy, wyx, axx * w);
 }
 
-// d * exp(-2 pi i k16 / 16), k16 a compile-time constant after unrolling
+// d * exp(-2 pi i k16 / 16), k16 (0..15) a compile-time constant after unrolling.  -i is ONE packed
+// multiply (the re/im swap is an op_sel modifier, the constant pair {1, -1} sits in SGPRs); every
+// other twiddle, the W8 family included, is multiply + fma = 2 packed ops.  (Spelling the W8 ones as
+// (x + y) * H, (y - x) * H compiles to 4 instructions: two packed adds, a move and a multiply.)
 __device__ __forceinline__ f32x2 mul_w16(f32x2 d, int k16) {
-  constexpr float C1 = 0.92387953251128675613f, S1 = 0.38268343236508977173f;
-  constexpr float H = 0.70710678118654752440f;
-  f32x2 r;
-  switch (k16) {
-    case 0: return d;
-    case 4: r.x = d.y; r.y = -d.x; return r;
-    case 2: r.x = (d.x + d.y) * H; r.y = (d.y - d.x) * H; return r;
-    case 6: r.x = (d.y - d.x) * H; r.y = -(d.x + d.y) * H; return r;
-    case 1: r.x = d.x * C1 + d.y * S1; r.y = d.y * C1 - d.x * S1; return r;
-    case 3: r.x = d.x * S1 + d.y * C1; r.y = d.y * S1 - d.x * C1; return r;
-    case 5: r.x = d.y * C1 - d.x * S1; r.y = -d.y * S1 - d.x * C1; return r;
-    default: r.x = d.y * S1 - d.x * C1; r.y = -d.y * C1 - d.x * S1; return r;  // 7
-  }
+  constexpr float C1 = 0.92387953251128675613f, S1 = 0.38268343236508977173f, H = 0.70710678118654752440f;
+  constexpr float C[16] = {1.0f, C1, H, S1, 0.0f, -S1, -H, -C1, -1.0f, -C1, -H, -S1, 0.0f, S1, H, C1};
+  constexpr float S[16] = {0.0f, S1, H, C1, 1.0f, C1, H, S1, 0.0f, -S1, -H, -C1, -1.0f, -C1, -H, -S1};
+  if (k16 == 0) return d;
+  const f32x2 dyx = {d.y, d.x};
+  if (k16 == 4) return dyx * f32x2{1.0f, -1.0f};
+  const f32x2 ss = {S[k16], -S[k16]}, cc = {C[k16], C[k16]};
+  return __builtin_elementwise_fma(dyx, ss, d * cc);
 }
 
 // 2^W-point DIF DFT on x[g*2^W .. ), output q at position bitrev_W(q)
 template <int W>
 __device__ __forceinline__ void dft_dif(f32x2 (&x)[16], int g) {
+  if constexpr (W == 4) {
+    // 16 points as two radix-4 stages (= the radix-2 stages fused in pairs, same output positions):
+    // the +-i rotations inside a radix-4 butterfly are fma(swap(d1), {+-1, -+1}, d0) -- one packed op
+    // each instead of a rotation plus an add -- and only 9 of the 16 outputs of the first stage carry
+    // a twiddle.  81 packed ops per 16 points against 110 for four radix-2 stages.
+    const f32x2 pm = {1.0f, -1.0f}, mp = {-1.0f, 1.0f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const f32x2 x0 = x[g * 16 + r], x4 = x[g * 16 + r + 4], x8 = x[g * 16 + r + 8], x12 = x[g * 16 + r + 12];
+      const f32x2 s0 = x0 + x8, d0 = x0 - x8, s1 = x4 + x12, d1 = x4 - x12;
+      const f32x2 d1s = {d1.y, d1.x};
+      x[g * 16 + r] = s0 + s1;
+      x[g * 16 + r + 4] = mul_w16(s0 - s1, 2 * r);
+      x[g * 16 + r + 8] = mul_w16(__builtin_elementwise_fma(d1s, pm, d0), r);       // (d0 - i d1) W^r
+      x[g * 16 + r + 12] = mul_w16(__builtin_elementwise_fma(d1s, mp, d0), 3 * r);  // (d0 + i d1) W^3r
+    }
+#pragma unroll
+    for (int b = 0; b < 16; b += 4) {
+      const f32x2 y0 = x[g * 16 + b], y1 = x[g * 16 + b + 1], y2 = x[g * 16 + b + 2], y3 = x[g * 16 + b + 3];
+      const f32x2 s0 = y0 + y2, d0 = y0 - y2, s1 = y1 + y3, d1 = y1 - y3;
+      const f32x2 d1s = {d1.y, d1.x};
+      x[g * 16 + b] = s0 + s1;
+      x[g * 16 + b + 1] = s0 - s1;
+      x[g * 16 + b + 2] = __builtin_elementwise_fma(d1s, pm, d0);
+      x[g * 16 + b + 3] = __builtin_elementwise_fma(d1s, mp, d0);
+    }
+    return;
+  }
 #pragma unroll
   for (int st = 0; st < W; ++st) {
     const int bl = W - 1 - st;

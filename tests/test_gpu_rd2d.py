@@ -74,7 +74,8 @@ def test_rd2d_run_time_windows(gpu, rr, gr, rd, gd, edge):
 @pytest.mark.parametrize("edge", ["zero", "wrap"])
 def test_rd2d_walker_agrees_with_tiled_kernel(gpu, edge, monkeypatch):
     """The register-ring strip walker (compile-time windows) and the tiled LDS kernel are two
-    summation orders of the same statistic: thresholds agree to a few ulp, peaks wherever decided."""
+    summation orders of the same statistic (the walker's column sums are running sums over 64 rows):
+    thresholds agree to ~1e-5, peaks wherever decided."""
     nr, nd, n_ch = 1024, 256, 2
     params = rd_params(nr, nd, edge=edge)
     rt = R.RunTimeRspChainParams(fftSize=nr, CFARMode="Cell Averaging", refWindowSize=8, guardWindowSize=2, divSum=4,
@@ -89,7 +90,7 @@ def test_rd2d_walker_agrees_with_tiled_kernel(gpu, edge, monkeypatch):
             outs.append(dut.stream(x))
     ta, pa = R.unpack_output_f32(outs[0])
     tb, pb = R.unpack_output_f32(outs[1])
-    np.testing.assert_allclose(ta, tb, rtol=4e-6)
+    np.testing.assert_allclose(ta, tb, rtol=1e-5)   # half the tolerance each is held to against the oracle
     assert np.mean(pa != pb) < 1e-4
 
 
