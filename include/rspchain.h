@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define RSP_ABI_VERSION 1
+#define RSP_ABI_VERSION 2
 #define RSP_MAX_STAGES 16
 
 enum {
@@ -178,23 +178,33 @@ int rsp_chain_process(rsp_chain* c, const void* in_beats, size_t n_frames, uint3
 /* Same with buffers already resident in HBM; asynchronous on the chain's stream. */
 int rsp_chain_process_device(rsp_chain* c, const void* d_in_beats, size_t n_frames,
                              uint32_t* d_out_words);
-/* Fused form: one pass produces the dense words (d_out_words may be NULL to skip
- * them: detection-list-only output, 8 B read per cell and no dense write) AND the
- * compact detection list.  Each frame contributes at most RSP_FRAME_DET_CAP peaks
- * to the list; *d_count (device uint32) still counts every peak found, so
- * *d_count > entries stored reveals truncation (by cap or by the per-frame limit). */
+/* Fused form: one pass produces the dense words AND the compact detection list.
+ * d_count points at TWO device uint32: d_count[0] = peaks found, d_count[1] = entries
+ * stored in d_list (<= cap); stored < found means the list is truncated.  With dense
+ * words the list is complete up to cap (the reference emits every peak, Tester:145-167).
+ * d_out_words may be NULL: detection-list-only output (8 B read per cell, no dense
+ * write); then a frame contributes at most RSP_FRAME_DET_CAP peaks (the kernel's
+ * per-frame staging) and d_count[1] < d_count[0] tells when that limit hit. */
 #define RSP_FRAME_DET_CAP 64
 int rsp_chain_process_detect_device(rsp_chain* c, const void* d_in_beats, size_t n_frames,
                                     uint32_t* d_out_words, rsp_detection* d_list, uint32_t cap,
                                     uint32_t* d_count);
 /* Compact the peak cells of a dense device result into list[0..cap) (device
- * memory); *d_count (device uint32) receives the number found (may exceed cap;
- * only cap entries are stored).  Order within the list is unspecified. */
+ * memory); d_count[0] (device uint32[2]) receives the number found (may exceed cap),
+ * d_count[1] the number stored.  Order within the list is unspecified. */
 int rsp_chain_detections_device(rsp_chain* c, const uint32_t* d_out_words, size_t n_frames,
                                 rsp_detection* d_list, uint32_t cap, uint32_t* d_count);
-/* Host-buffer convenience: dense process + compaction; list sorted by (frame, doppler, bin). */
+/* Host-buffer convenience: dense process + compaction (complete: no per-frame limit);
+ * list sorted by (frame, doppler, bin); *n_found may exceed cap, min(*n_found, cap) entries are returned. */
 int rsp_chain_process_detections(rsp_chain* c, const void* in_beats, size_t n_frames,
                                  rsp_detection* list, size_t cap, size_t* n_found);
+
+/* Tuning / test knobs (no reference counterpart; replaces environment variables of round 1). */
+enum {
+  RSP_OPT_MAX_FRAMES_PER_LAUNCH = 1, /* split a call into launches of at most this many frames (0 = automatic) */
+  RSP_OPT_FORCE_TILED_CFAR2D = 2     /* 2-D chain: run-time-window CFAR kernel even for the compile-time windows */
+};
+int rsp_chain_set_option(rsp_chain* c, int option, int64_t value);
 
 /* --- stream / memory / timing plumbing -------------------------------------- */
 /* Run on a caller-owned hipStream_t (e.g. the stream a host framework is already using); NULL restores

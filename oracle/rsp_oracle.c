@@ -411,12 +411,23 @@ void orc_cfar_f64(const double* mag, const orc_fcfg* c, double* thr, uint8_t* pe
     double t = c->linear ? stat * c->scaler : stat + c->scaler;
     double cut = mag[k];
     int p = cut > t;
+    /* margin = how far the inputs of the decision may move before the flag can flip.  The flag
+     * is an AND of comparisons: a set flag flips when its weakest comparison flips; a clear flag
+     * stays clear as long as ANY failing comparison keeps failing, so its margin is the largest
+     * margin among the failing ones (a neighbour cannot turn a cell with cut <= thr into a peak). */
     double mg = fabs(cut - t);
     if (c->peak_grouping) {
       int jl = cell_index(k, -1, n, c->edge), jr = cell_index(k, 1, n, c->edge);
       double l = jl < 0 ? 0.0 : mag[jl], r = jr < 0 ? 0.0 : mag[jr];
-      p = p && cut > l && cut > r;
-      mg = dmin(mg, dmin(fabs(cut - l), fabs(cut - r)));
+      double d[3] = {cut - t, cut - l, cut - r};
+      p = d[0] > 0.0 && d[1] > 0.0 && d[2] > 0.0;
+      if (p) {
+        mg = dmin(d[0], dmin(d[1], d[2]));
+      } else {
+        mg = 0.0;
+        for (int q = 0; q < 3; q++)
+          if (!(d[q] > 0.0) && -d[q] > mg) mg = -d[q];
+      }
     }
     thr[k] = t;
     peak[k] = (uint8_t)p;

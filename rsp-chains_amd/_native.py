@@ -93,6 +93,7 @@ SIGNATURES = {
     "rsp_chain_process_detect_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "rsp_chain_detections_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_void_p]),
     "rsp_chain_process_detections": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _P(C.c_size_t)]),
+    "rsp_chain_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int64]),
     "rsp_chain_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rsp_chain_synchronize": (C.c_int, [C.c_void_p]),
     "rsp_chain_timer_start": (C.c_int, [C.c_void_p]),

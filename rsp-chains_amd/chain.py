@@ -342,8 +342,10 @@ class FftMagCfarChainVanilla:
         return out.reshape(-1, n)
 
     def detections(self, beats, cap: int = 1 << 20):
+        """Host-buffer convenience: (sorted detection records, number of peaks found).  Complete: frames
+        with more than RSP_FRAME_DET_CAP peaks are finished from the dense words on the device."""
         a = self._as_beats(beats)
-        n = self.fftSize
+        n = self.frameCells
         lst = (N.Detection * cap)()
         found = C.c_size_t()
         _check(self._lib.rsp_chain_process_detections(self._h, a.ctypes.data_as(C.c_void_p), a.size // n,
@@ -358,7 +360,8 @@ class FftMagCfarChainVanilla:
         _check(self._lib.rsp_chain_process_device(self._h, C.c_void_p(d_in), n_frames, C.c_void_p(d_out)))
 
     def process_detect_device(self, d_in: int, n_frames: int, d_out: int, d_list: int, cap: int, d_count: int):
-        """Fused dense words (d_out may be 0 = skip) + compact detection list."""
+        """Fused dense words (d_out may be 0 = skip) + compact detection list.  d_count -> two device
+        uint32: {peaks found, entries stored}."""
         _check(self._lib.rsp_chain_process_detect_device(self._h, C.c_void_p(d_in), n_frames,
                                                          C.c_void_p(d_out) if d_out else None,
                                                          C.c_void_p(d_list), cap, C.c_void_p(d_count)))
@@ -366,6 +369,11 @@ class FftMagCfarChainVanilla:
     def detections_device(self, d_words: int, n_frames: int, d_list: int, cap: int, d_count: int):
         _check(self._lib.rsp_chain_detections_device(self._h, C.c_void_p(d_words), n_frames,
                                                      C.c_void_p(d_list), cap, C.c_void_p(d_count)))
+
+    MAX_FRAMES_PER_LAUNCH, FORCE_TILED_CFAR2D = 1, 2   # RSP_OPT_* of include/rspchain.h
+
+    def set_option(self, option: int, value: int):
+        _check(self._lib.rsp_chain_set_option(self._h, option, value))
 
     def set_stream(self, hip_stream: int):
         _check(self._lib.rsp_chain_set_stream(self._h, C.c_void_p(hip_stream)))

@@ -14,7 +14,6 @@
 // long-range cancellation for fp32.
 #include <hip/hip_runtime.h>
 #include <float.h>
-#include <stdlib.h>
 
 #include "chain_regs.hpp"
 #include "fft_lds.hpp"
@@ -353,14 +352,8 @@ template <int M, bool FIXED>
 __global__ void __launch_bounds__(wg_size(M))
 chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t n_frames,
                ChainRegs rg, const void* __restrict__ tw, const int16_t* __restrict__ log_lut,
-               uint32_t* __restrict__ fcount, uint2* __restrict__ fdet,
-               uint32_t* __restrict__ zero_a, uint32_t* __restrict__ zero_b) {
+               uint32_t* __restrict__ fcount, uint2* __restrict__ fdet) {
   constexpr int N = 1 << M, T = threads_per_frame(M), FPW = frames_per_wg(M), NP = plan_np(M);
-  // counters of the compaction launch that follows on this stream (saves two memset nodes)
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (zero_a) *zero_a = 0u;
-    if (zero_b) *zero_b = 0u;
-  }
   using L = FrameLds<M>;
   using V = typename std::conditional<FIXED, int, float>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -649,13 +642,8 @@ __global__ void __launch_bounds__(wg_size(M))
 chain1d_gos_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t n_frames,
                    ChainRegs rg, GosLayout lay, const void* __restrict__ tw,
                    const int16_t* __restrict__ log_lut, uint32_t* __restrict__ fcount,
-                   uint2* __restrict__ fdet, uint32_t* __restrict__ zero_a,
-                   uint32_t* __restrict__ zero_b) {
+                   uint2* __restrict__ fdet) {
   constexpr int N = 1 << M, T = threads_per_frame(M), FPW = frames_per_wg(M);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (zero_a) *zero_a = 0u;
-    if (zero_b) *zero_b = 0u;
-  }
   using V = typename std::conditional<FIXED, int, float>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -744,19 +732,20 @@ static hipError_t launch_gos(const Chain1dLaunch& a) {
   const GosLayout lay = gos_layout<M>(a.regs);
   const size_t lds = (size_t)lay.frame_bytes * fpw + (a.fixed ? FrameLds<M>::ROM_BYTES : 0);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
+  static LdsGrant granted[2];
   hipError_t e;
   if (a.fixed) {
     auto k = chain1d_gos_kernel<M, true>;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    e = grant_lds(k, lds, a.device, granted[0]);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(wg_size(M)), lds, a.stream, a.in, a.out, a.n_frames, a.regs, lay,
-                       a.twiddles, a.log_lut, a.frame_count, a.frame_det, a.zero_a, a.zero_b);
+                       a.twiddles, a.log_lut, a.frame_count, a.frame_det);
   } else {
     auto k = chain1d_gos_kernel<M, false>;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    e = grant_lds(k, lds, a.device, granted[1]);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(wg_size(M)), lds, a.stream, a.in, a.out, a.n_frames, a.regs, lay,
-                       a.twiddles, a.log_lut, a.frame_count, a.frame_det, a.zero_a, a.zero_b);
+                       a.twiddles, a.log_lut, a.frame_count, a.frame_det);
   }
   return hipGetLastError();
 }
@@ -766,26 +755,20 @@ static hipError_t launch_m(const Chain1dLaunch& a) {
   if (a.regs.algorithm == 1) return launch_gos<M>(a);
   const uint32_t fpw = frames_per_wg(M);
   const uint32_t grid = (a.n_frames + fpw - 1) / fpw;
-  size_t lds = FrameLds<M>::BYTES * fpw + (a.fixed ? FrameLds<M>::ROM_BYTES : 0);
-  if (const char* ex = getenv("RSP_DEBUG_EXTRA_LDS")) lds += (size_t)atoi(ex);  // occupancy experiments only
+  const size_t lds = FrameLds<M>::BYTES * fpw + (a.fixed ? FrameLds<M>::ROM_BYTES : 0);
+  static LdsGrant granted[2];
   if (a.fixed) {
     auto k = chain1d_kernel<M, true>;
-    if (lds > 48 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-    }
+    hipError_t e = grant_lds(k, lds, a.device, granted[0]);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(wg_size(M)), lds, a.stream, a.in, a.out, a.n_frames,
-                       a.regs, a.twiddles, a.log_lut, a.frame_count, a.frame_det, a.zero_a, a.zero_b);
+                       a.regs, a.twiddles, a.log_lut, a.frame_count, a.frame_det);
   } else {
     auto k = chain1d_kernel<M, false>;
-    if (lds > 48 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-    }
+    hipError_t e = grant_lds(k, lds, a.device, granted[1]);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(wg_size(M)), lds, a.stream, a.in, a.out, a.n_frames,
-                       a.regs, a.twiddles, a.log_lut, a.frame_count, a.frame_det, a.zero_a, a.zero_b);
+                       a.regs, a.twiddles, a.log_lut, a.frame_count, a.frame_det);
   }
   return hipGetLastError();
 }
@@ -796,7 +779,10 @@ hipError_t launch_chain1d(const Chain1dLaunch& a0) {
   // kernels address a launch's input with 32-bit byte offsets: split into < 4 GiB pieces
   const uint64_t beat = a0.fixed ? 4 : 8;
   uint32_t max_frames = (uint32_t)((0xFFFFFFFFull / (beat << a0.log2n)) & ~63ull);
-  if (const char* dbg = getenv("RSP_DEBUG_MAX_FRAMES")) max_frames = (uint32_t)atoi(dbg);  // tests only
+  if (a0.max_frames_per_launch) {  // whole workgroups only, never zero
+    const uint32_t want = (a0.max_frames_per_launch + 63u) & ~63u;
+    if (want < max_frames) max_frames = want;
+  }
   Chain1dLaunch a = a0;
   for (uint32_t done = 0; done < a0.n_frames; done += max_frames) {
     a.n_frames = a0.n_frames - done < max_frames ? a0.n_frames - done : max_frames;
@@ -804,13 +790,7 @@ hipError_t launch_chain1d(const Chain1dLaunch& a0) {
     a.out = a0.out ? a0.out + ((uint64_t)done << a0.log2n) : nullptr;
     a.frame_count = a0.frame_count ? a0.frame_count + done : nullptr;
     a.frame_det = a0.frame_det ? a0.frame_det + (uint64_t)done * kFrameDetCap : nullptr;
-    if (done) a.zero_a = a.zero_b = nullptr;
     hipError_t e;
-    if (chain1d_wave_supports(a)) {  // opt-in alternative formulation (chain1d_wave.hip)
-      e = launch_chain1d_wave(a);
-      if (e != hipSuccess) return e;
-      continue;
-    }
     switch (a.log2n) {
       case 8: e = launch_m<8>(a); break;
       case 9: e = launch_m<9>(a); break;
@@ -827,20 +807,44 @@ hipError_t launch_chain1d(const Chain1dLaunch& a0) {
 
 // ---------------------------------------------------------------- detection compaction
 
+// Last-workgroup epilogue shared by both compaction kernels: counters = {found, cursor, ticket}, all
+// zero on entry.  Every workgroup has added its share (device-scope atomics) before it takes a
+// ticket; the workgroup that draws the last ticket publishes {found, stored} and re-zeroes the
+// counters for the next launch on this stream.
+__device__ __forceinline__ void publish_counts(uint32_t* counters, uint32_t cap, uint32_t* d_count) {
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t ticket = atomicAdd(&counters[2], 1u);
+    if (ticket == gridDim.x - 1) {
+      __threadfence();
+      const uint32_t found = atomicExch(&counters[0], 0u);
+      const uint32_t cursor = atomicExch(&counters[1], 0u);
+      atomicExch(&counters[2], 0u);
+      d_count[0] = found;
+      d_count[1] = cursor < cap ? cursor : cap;
+    }
+  }
+}
+
 // Per-frame slots written by chain1d_kernel -> one compact list.  One thread per
-// frame, 256 frames per workgroup, ONE global atomic per workgroup (a block of
+// frame, 256 frames per workgroup, ONE global atomic per counter per workgroup (a block of
 // the list is reserved from the scanned per-frame counts).
-// counters[0] = list allocation cursor (zeroed by the chain kernel), *d_count = peaks found.
 __global__ void __launch_bounds__(256)
 compact_frames_kernel(const uint32_t* __restrict__ fcount, const uint2* __restrict__ fdet,
-                      uint32_t n_frames, rsp_detection* __restrict__ list, uint32_t cap,
+                      uint32_t n_frames, const uint32_t* __restrict__ words, int log2n,
+                      rsp_detection* __restrict__ list, uint32_t cap,
                       uint32_t* __restrict__ counters, uint32_t* __restrict__ d_count) {
-  __shared__ uint32_t wave_tot[4];
-  __shared__ uint32_t base_sh;
+  __shared__ uint32_t wave_tot[4], wave_found[4];
+  __shared__ uint32_t base_sh, ovf_n, ovf_cursor;
+  __shared__ uint32_t ovf_frame[256], ovf_base[256];
   const uint32_t f = blockIdx.x * 256 + threadIdx.x;
   const uint32_t found = f < n_frames ? fcount[f] : 0u;
-  const uint32_t mine = min(found, (uint32_t)kFrameDetCap);
+  // a frame whose peaks did not fit its slots is re-read from the dense words when there are any
+  const bool ovf = found > (uint32_t)kFrameDetCap;
+  const uint32_t mine = (ovf && !words) ? (uint32_t)kFrameDetCap : found;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) ovf_n = 0u;
   uint32_t inc = mine, tot_found = found;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -850,34 +854,67 @@ compact_frames_kernel(const uint32_t* __restrict__ fcount, const uint2* __restri
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) tot_found += __shfl_xor(tot_found, d);
   if (lane == 63) wave_tot[wave] = inc;
+  if (lane == 0) wave_found[wave] = tot_found;
   __syncthreads();
   uint32_t off = inc - mine;
   for (int w = 0; w < wave; ++w) off += wave_tot[w];
-  if (lane == 0 && tot_found) atomicAdd(d_count, tot_found);
   if (threadIdx.x == 0) {
     const uint32_t tot = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-    base_sh = tot ? atomicAdd(&counters[0], tot) : 0u;
+    const uint32_t fnd = wave_found[0] + wave_found[1] + wave_found[2] + wave_found[3];
+    if (fnd) atomicAdd(&counters[0], fnd);
+    base_sh = tot ? atomicAdd(&counters[1], tot) : 0u;
   }
   __syncthreads();
   const uint32_t base = base_sh + off;
-  for (uint32_t i = 0; i < mine; ++i) {
-    if (base + i >= cap) break;
-    const uint2 e = fdet[(size_t)f * kFrameDetCap + i];
-    rsp_detection d;
-    d.frame = f;
-    d.bin = e.x;
-    d.doppler = 0;
-    d.word = e.y;
-    list[base + i] = d;
+  if (ovf && words) {
+    const uint32_t s = atomicAdd(&ovf_n, 1u);
+    ovf_frame[s] = f;
+    ovf_base[s] = base;
+  } else {
+    for (uint32_t i = 0; i < mine; ++i) {
+      if (base + i >= cap) break;
+      const uint2 e = fdet[(size_t)f * kFrameDetCap + i];
+      rsp_detection d;
+      d.frame = f;
+      d.bin = e.x;
+      d.doppler = 0;
+      d.word = e.y;
+      list[base + i] = d;
+    }
   }
+  __syncthreads();
+  // overflow frames (rare: > kFrameDetCap peaks in one frame): the whole workgroup re-reads the frame
+  const uint32_t n_ovf = ovf_n;
+  for (uint32_t q = 0; q < n_ovf; ++q) {
+    if (threadIdx.x == 0) ovf_cursor = 0u;
+    __syncthreads();
+    const uint32_t of = ovf_frame[q], ob = ovf_base[q];
+    const uint32_t* row = words + ((size_t)of << log2n);
+    for (uint32_t x = threadIdx.x; x < (1u << log2n); x += 256) {
+      const uint32_t w = row[x];
+      if (w & 1u) {
+        const uint32_t slot = ob + atomicAdd(&ovf_cursor, 1u);
+        if (slot < cap) {
+          rsp_detection d;
+          d.frame = of;
+          d.bin = x;
+          d.doppler = 0;
+          d.word = w;
+          list[slot] = d;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  publish_counts(counters, cap, d_count);
 }
 
 hipError_t launch_compact_frames(const uint32_t* fcount, const uint2* fdet, uint32_t n_frames,
-                                 rsp_detection* list, uint32_t cap, uint32_t* counters,
-                                 uint32_t* d_count, hipStream_t stream) {
-  if (n_frames == 0) return hipSuccess;
+                                 const uint32_t* words, int log2n, rsp_detection* list, uint32_t cap,
+                                 uint32_t* counters, uint32_t* d_count, hipStream_t stream) {
+  if (n_frames == 0) return hipMemsetAsync(d_count, 0, 2 * sizeof(uint32_t), stream);
   hipLaunchKernelGGL(compact_frames_kernel, dim3((n_frames + 255) / 256), dim3(256), 0, stream,
-                     fcount, fdet, n_frames, list, cap, counters, d_count);
+                     fcount, fdet, n_frames, words, log2n, list, cap, counters, d_count);
   return hipGetLastError();
 }
 
@@ -887,7 +924,7 @@ hipError_t launch_compact_frames(const uint32_t* fcount, const uint2* fdet, uint
 __global__ void __launch_bounds__(256)
 compact_kernel(const uint32_t* __restrict__ words, uint64_t n_cells, uint64_t cells_per_wg,
                uint32_t log2_row, uint32_t log2_rows_per_frame, rsp_detection* __restrict__ list,
-               uint32_t cap, uint32_t* __restrict__ count) {
+               uint32_t cap, uint32_t* __restrict__ counters, uint32_t* __restrict__ d_count) {
   __shared__ uint32_t wave_cnt[4];
   __shared__ uint32_t base_sh;
   const uint64_t lo = (uint64_t)blockIdx.x * cells_per_wg;
@@ -902,7 +939,8 @@ compact_kernel(const uint32_t* __restrict__ words, uint64_t n_cells, uint64_t ce
   __syncthreads();
   if (threadIdx.x == 0) {
     const uint32_t t = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-    base_sh = t ? atomicAdd(count, t) : 0u;
+    if (t) atomicAdd(&counters[0], t);
+    base_sh = t ? atomicAdd(&counters[1], t) : 0u;
     wave_cnt[0] = 0;  // becomes the in-workgroup cursor
   }
   __syncthreads();
@@ -921,19 +959,18 @@ compact_kernel(const uint32_t* __restrict__ words, uint64_t n_cells, uint64_t ce
       }
     }
   }
+  publish_counts(counters, cap, d_count);
 }
 
 hipError_t launch_compact(const uint32_t* words, uint64_t n_cells, uint32_t log2_row,
                           uint32_t log2_rows_per_frame, rsp_detection* list, uint32_t cap,
-                          uint32_t* count, hipStream_t stream) {
-  hipError_t e = hipMemsetAsync(count, 0, sizeof(uint32_t), stream);
-  if (e != hipSuccess) return e;
-  if (n_cells == 0) return hipSuccess;
+                          uint32_t* counters, uint32_t* d_count, hipStream_t stream) {
+  if (n_cells == 0) return hipMemsetAsync(d_count, 0, 2 * sizeof(uint32_t), stream);
   uint64_t blocks = (n_cells + 4095) / 4096;
   if (blocks > 4096) blocks = 4096;
   const uint64_t per = (n_cells + blocks - 1) / blocks;
   hipLaunchKernelGGL(compact_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, words, n_cells,
-                     per, log2_row, log2_rows_per_frame, list, cap, count);
+                     per, log2_row, log2_rows_per_frame, list, cap, counters, d_count);
   return hipGetLastError();
 }
 

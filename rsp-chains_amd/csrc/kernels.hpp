@@ -22,16 +22,13 @@ struct Chain1dLaunch {
   // optional fused detection output: per-frame peak count + first kFrameDetCap {bin, word}
   uint32_t* frame_count;   // device: n_frames, or NULL
   uint2* frame_det;        // device: n_frames x kFrameDetCap
-  uint32_t* zero_a;        // device words zeroed by block 0 (the compaction launch's counters), or NULL
-  uint32_t* zero_b;
   hipStream_t stream;
+  int device;                    // HIP ordinal the launch runs on (per-device one-time kernel attributes)
+  uint32_t max_frames_per_launch;  // 0 = as many as 32-bit byte offsets allow; tests force the split path
 };
 
 hipError_t launch_chain1d(const Chain1dLaunch& a);
-hipError_t launch_chain1d_small(const Chain1dLaunch& a);
-// F32 4096-point CA/GO/SO frames, one wave per frame (chain1d_wave.hip)
-bool chain1d_wave_supports(const Chain1dLaunch& a);
-hipError_t launch_chain1d_wave(const Chain1dLaunch& a);  // 16..128-point frames (small.hip)
+hipError_t launch_chain1d_small(const Chain1dLaunch& a);  // 16..128-point frames (small.hip)
 size_t chain1d_lds_bytes(int log2n);
 
 // 2-D range-Doppler chain (rd2d.hip): in [n_ch][nd][nr] complex64 -> out [n_ch][nd][nr] words
@@ -47,15 +44,43 @@ struct Rd2dLaunch {
   void* scratch_complex;  // device: n_ch * nd * nr * 8 B
   float* scratch_mag;     // device: n_ch * nd * nr * 4 B
   hipStream_t stream;
+  int device;
+  bool force_tiled_cfar;  // tests: take the run-time-window kernel even for the compile-time windows
 };
 hipError_t launch_rd2d(const Rd2dLaunch& a);
 
+// Detection compaction.  `counters` = 3 device words owned by the chain handle {found, cursor, ticket},
+// zero between launches: the last workgroup to finish publishes d_count[0] = peaks found,
+// d_count[1] = entries stored in list (<= cap) and zeroes them again -- no memset node, and the chain
+// kernel does not have to touch them.
+constexpr int kCompactCounters = 3;
+// per-frame slots of the fused path -> list.  A frame with more than kFrameDetCap peaks is re-read from
+// its dense words when `words` is given (complete list); without dense words it contributes its first
+// kFrameDetCap peaks and d_count[1] < d_count[0] tells.
 hipError_t launch_compact_frames(const uint32_t* fcount, const uint2* fdet, uint32_t n_frames,
-                                 rsp_detection* list, uint32_t cap, uint32_t* counters,
-                                 uint32_t* d_count, hipStream_t stream);
+                                 const uint32_t* words, int log2n, rsp_detection* list, uint32_t cap,
+                                 uint32_t* counters, uint32_t* d_count, hipStream_t stream);
 
 hipError_t launch_compact(const uint32_t* words, uint64_t n_cells, uint32_t log2_row,
                           uint32_t log2_rows_per_frame, rsp_detection* list, uint32_t cap,
-                          uint32_t* count, hipStream_t stream);
+                          uint32_t* counters, uint32_t* d_count, hipStream_t stream);
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device), not per launch:
+// `granted` is a function-local static of the launcher that owns the instantiation.
+constexpr int kMaxDevices = 16;
+struct LdsGrant {
+  uint32_t bytes[kMaxDevices] = {};
+};
+template <typename K>
+inline hipError_t grant_lds(K kernel, size_t lds, int device, LdsGrant& granted) {
+  if (lds <= 48 * 1024) return hipSuccess;  // within the default limit
+  if (device < 0 || device >= kMaxDevices) device = kMaxDevices - 1;  // shared slot: still correct, set again
+  // benign race between host threads of different handles: both would set the same attribute
+  if (granted.bytes[device] >= lds && device != kMaxDevices - 1) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e == hipSuccess) granted.bytes[device] = (uint32_t)lds;
+  return e;
+}
 
 }  // namespace rsp

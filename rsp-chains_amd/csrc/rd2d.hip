@@ -15,7 +15,6 @@
 // crosses workgroup tiles in range; fusing it means recomputing halo columns' FFTs).
 #include <hip/hip_runtime.h>
 #include <float.h>
-#include <stdlib.h>
 
 #include "chain_regs.hpp"
 #include "fft_lds.hpp"
@@ -311,27 +310,25 @@ cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, ui
 
 template <int M>
 static hipError_t launch_range_m(const f32x2* in, f32x2* out, uint32_t n_rows, const f32x2* tw,
-                                 hipStream_t s) {
+                                 hipStream_t s, int device) {
   const uint32_t fpw = frames_per_wg(M);
   const size_t lds = (size_t)8 * pad_slots(1 << M) * fpw;
   auto k = range_fft_kernel<M>;
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-  }
+  static LdsGrant granted;
+  hipError_t e = grant_lds(k, lds, device, granted);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3((n_rows + fpw - 1) / fpw), dim3(wg_size(M)), lds, s, in, out, n_rows, tw);
   return hipGetLastError();
 }
 
 template <int MD>
 static hipError_t launch_doppler_m(const f32x2* in, float* mag, uint32_t n_ch, uint32_t nr, int mode,
-                                   const f32x2* tw, hipStream_t s) {
+                                   const f32x2* tw, hipStream_t s, int device) {
   constexpr int C = kColsPerWg(MD);
   const size_t lds = (size_t)kColBytes(MD) * C;
   auto k = doppler_mag_kernel<MD>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static LdsGrant granted;
+  hipError_t e = grant_lds(k, lds, device, granted);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3(n_ch * (nr / C)), dim3(threads_per_frame(MD) * C), lds, s, in, mag, n_ch,
                      nr, mode, tw);
@@ -348,19 +345,19 @@ hipError_t launch_rd2d(const Rd2dLaunch& a) {
   const f32x2* twd = reinterpret_cast<const f32x2*>(a.tw_doppler);
   const uint32_t rows = a.n_ch * nd;
   switch (a.log2nr) {
-    case 8: e = launch_range_m<8>(in, x1, rows, twr, a.stream); break;
-    case 9: e = launch_range_m<9>(in, x1, rows, twr, a.stream); break;
-    case 10: e = launch_range_m<10>(in, x1, rows, twr, a.stream); break;
-    case 11: e = launch_range_m<11>(in, x1, rows, twr, a.stream); break;
-    case 12: e = launch_range_m<12>(in, x1, rows, twr, a.stream); break;
-    case 13: e = launch_range_m<13>(in, x1, rows, twr, a.stream); break;
+    case 8: e = launch_range_m<8>(in, x1, rows, twr, a.stream, a.device); break;
+    case 9: e = launch_range_m<9>(in, x1, rows, twr, a.stream, a.device); break;
+    case 10: e = launch_range_m<10>(in, x1, rows, twr, a.stream, a.device); break;
+    case 11: e = launch_range_m<11>(in, x1, rows, twr, a.stream, a.device); break;
+    case 12: e = launch_range_m<12>(in, x1, rows, twr, a.stream, a.device); break;
+    case 13: e = launch_range_m<13>(in, x1, rows, twr, a.stream, a.device); break;
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
   switch (a.log2nd) {
-    case 8: e = launch_doppler_m<8>(x1, a.scratch_mag, a.n_ch, nr, a.regs.mag_mode, twd, a.stream); break;
-    case 9: e = launch_doppler_m<9>(x1, a.scratch_mag, a.n_ch, nr, a.regs.mag_mode, twd, a.stream); break;
-    case 10: e = launch_doppler_m<10>(x1, a.scratch_mag, a.n_ch, nr, a.regs.mag_mode, twd, a.stream); break;
+    case 8: e = launch_doppler_m<8>(x1, a.scratch_mag, a.n_ch, nr, a.regs.mag_mode, twd, a.stream, a.device); break;
+    case 9: e = launch_doppler_m<9>(x1, a.scratch_mag, a.n_ch, nr, a.regs.mag_mode, twd, a.stream, a.device); break;
+    case 10: e = launch_doppler_m<10>(x1, a.scratch_mag, a.n_ch, nr, a.regs.mag_mode, twd, a.stream, a.device); break;
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
@@ -370,7 +367,7 @@ hipError_t launch_rd2d(const Rd2dLaunch& a) {
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const float kA = a.regs.linear ? a.regs.scaler_f : 1.0f, kB = a.regs.linear ? 0.0f : a.regs.scaler_f;
   const bool spec = a.regs.R == 8 && a.regs.G == 2 && a.ref_d == 8 && a.guard_d == 2;  // cfg 3 / cfg 5
-  if (spec && !getenv("RSP_DEBUG_NO_WALK")) {
+  if (spec && !a.force_tiled_cfar) {
     const uint32_t strips = (nr + walk_outw(10) - 1) / walk_outw(10);
     // 64 rows per wave: 32 measures the same, 128 is 6 % slower (fewer waves to hide the row latency)
     constexpr uint32_t SEG = 64;
@@ -379,7 +376,8 @@ hipError_t launch_rd2d(const Rd2dLaunch& a) {
     return hipGetLastError();
   }
   auto k = cfar2d_kernel<-1, -1, -1, -1>;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static LdsGrant granted;
+  e = grant_lds(k, lds, a.device, granted);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3(a.n_ch * (nr / kTR) * (nd / kTD)), dim3(256), lds, a.stream, a.scratch_mag, a.out,
                      nd, nr, a.regs.R, a.regs.G, a.ref_d, a.guard_d, a.regs.edge, kA, kB);

@@ -74,7 +74,8 @@ struct rsp_chain {
   size_t d_out_bytes = 0;
   rsp_detection* d_list = nullptr;
   size_t d_list_cap = 0;
-  uint32_t* d_count = nullptr;   // [0] found (host-API path), [1] list cursor of the fused path
+  uint32_t* d_count = nullptr;   // {found, stored} of the host-buffer detection call
+  uint32_t* d_ctr = nullptr;     // compaction counters {found, cursor, ticket}: zero between launches
   uint32_t* d_fcount = nullptr;  // per-frame peak counts of the fused path
   uint2* d_fdet = nullptr;       // per-frame peak slots
   size_t fslots = 0;             // frames the two buffers above hold
@@ -86,6 +87,9 @@ struct rsp_chain {
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
   size_t prof_used = 0;
+  // rsp_chain_set_option
+  uint32_t opt_max_frames = 0;
+  bool opt_force_tiled = false;
 };
 
 namespace {
@@ -271,7 +275,7 @@ rsp::ChainRegs snapshot(const rsp_chain* c) {
   r.idx_lagg = (int)c->cfar[kIndexLagg];
   r.idx_lead = (int)c->cfar[kIndexLead];
   r.sub_window = (int)c->cfar[kSubWindow];
-#ifdef RSP_ABLATE
+#ifdef RSP_ABLATE  // tools/ablate.sh side builds only
   if (const char* m = getenv("RSP_ABLATE_MASK")) r.sub_window = atoi(m);
 #endif
   r.edge = p.cfarParams.edgeMode;
@@ -371,11 +375,11 @@ int launch_dense(rsp_chain* c, const void* d_in, size_t n_frames, uint32_t* d_ou
   if (rc != RSP_OK) return rc;
   a.log_lut = c->d_log_lut;
   a.stream = c->stream;
+  a.device = c->device;
+  a.max_frames_per_launch = c->opt_max_frames;
   if (d_found) {
     a.frame_count = c->d_fcount;
     a.frame_det = c->d_fdet;
-    a.zero_a = c->d_count + 1;
-    a.zero_b = d_found;
   }
   hipEvent_t pe0 = nullptr, pe1 = nullptr;
   if (c->profiling) {
@@ -393,8 +397,8 @@ int launch_dense(rsp_chain* c, const void* d_in, size_t n_frames, uint32_t* d_ou
   HIP_TRY(rsp::launch_chain1d(a));
   if (pe1) HIP_TRY(hipEventRecord(pe1, c->stream));
   if (d_found)
-    HIP_TRY(rsp::launch_compact_frames(c->d_fcount, c->d_fdet, (uint32_t)n_frames, d_list, cap,
-                                       c->d_count + 1, d_found, c->stream));
+    HIP_TRY(rsp::launch_compact_frames(c->d_fcount, c->d_fdet, (uint32_t)n_frames, d_out, a.log2n, d_list, cap,
+                                       c->d_ctr, d_found, c->stream));
   return RSP_OK;
 }
 
@@ -424,7 +428,22 @@ int launch_rd(rsp_chain* c, const void* d_in, size_t n_ch, uint32_t* d_out) {
   a.scratch_complex = c->d_x1;
   a.scratch_mag = c->d_mag2;
   a.stream = c->stream;
+  a.device = c->device;
+  a.force_tiled_cfar = c->opt_force_tiled;
+  hipEvent_t pe1 = nullptr;
+  if (c->profiling) {  // the 2-D chain's three kernels as one bracket
+    if (c->prof_used == c->prof_events.size()) {
+      hipEvent_t e0, e1;
+      HIP_TRY(hipEventCreate(&e0));
+      HIP_TRY(hipEventCreate(&e1));
+      c->prof_events.emplace_back(e0, e1);
+    }
+    HIP_TRY(hipEventRecord(c->prof_events[c->prof_used].first, c->stream));
+    pe1 = c->prof_events[c->prof_used].second;
+    ++c->prof_used;
+  }
   HIP_TRY(rsp::launch_rd2d(a));
+  if (pe1) HIP_TRY(hipEventRecord(pe1, c->stream));
   return RSP_OK;
 }
 
@@ -508,7 +527,10 @@ int rsp_chain_create(const rsp_chain_params* p, rsp_chain** out) {
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(RSP_ERR_DEVICE, "hipStreamCreate failed"));
   c->stream = c->own_stream;
   if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return bail(fail(RSP_ERR_DEVICE, "hipEventCreate failed"));
-  if (hipMalloc(reinterpret_cast<void**>(&c->d_count), 2 * sizeof(uint32_t)) != hipSuccess) return bail(fail(RSP_ERR_DEVICE, "hipMalloc failed"));
+  if (hipMalloc(reinterpret_cast<void**>(&c->d_count), 2 * sizeof(uint32_t)) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&c->d_ctr), rsp::kCompactCounters * sizeof(uint32_t)) != hipSuccess ||
+      hipMemset(c->d_ctr, 0, rsp::kCompactCounters * sizeof(uint32_t)) != hipSuccess)
+    return bail(fail(RSP_ERR_DEVICE, "hipMalloc failed"));
   if (p->dtype == RSP_DTYPE_FIXED16) {
     // log2 fraction table of the logMagMux (MAGParams log2LookUpWidth / binPointLog,
     // FftMagCfarChain.scala:95-96); entry f = round(log2(1 + f / 2^lw) * 2^bpLog)
@@ -535,6 +557,7 @@ void rsp_chain_destroy(rsp_chain* c) {
   if (c->d_out) (void)hipFree(c->d_out);
   if (c->d_list) (void)hipFree(c->d_list);
   if (c->d_count) (void)hipFree(c->d_count);
+  if (c->d_ctr) (void)hipFree(c->d_ctr);
   if (c->d_fcount) (void)hipFree(c->d_fcount);
   if (c->d_fdet) (void)hipFree(c->d_fdet);
   if (c->d_x1) (void)hipFree(c->d_x1);
@@ -602,7 +625,7 @@ int rsp_chain_process_detect_device(rsp_chain* c, const void* d_in, size_t n_fra
   if (!d_count || (cap && !d_list)) return fail(RSP_ERR_INVALID, "NULL buffer");
   if (n_frames == 0) {
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(d_count, 0, 2 * sizeof(uint32_t), c->stream));
     return RSP_OK;
   }
   return launch_dense(c, d_in, n_frames, d_out_words, d_list, cap, d_count);
@@ -615,7 +638,10 @@ int rsp_chain_process(rsp_chain* c, const void* in_beats, size_t n_frames, uint3
   if (n_frames == 0) return RSP_OK;
   if (!in_beats || !out_words) return fail(RSP_ERR_INVALID, "NULL buffer");
   HIP_TRY(hipSetDevice(c->device));
+  if (n_frames > (c->p.dopplerPoints ? 0xffffull : 0x7fffffffull))
+    return fail(RSP_ERR_INVALID, "n_frames = %zu too large for one call", n_frames);
   const size_t cells = (n_frames * (size_t)(c->p.dopplerPoints ? c->p.dopplerPoints : 1)) << c->fft_stages;
+  if (c->p.dopplerPoints && cells > 0x7fffffffull) return fail(RSP_ERR_INVALID, "2-D chain: %zu channels too many for one call", n_frames);
   const size_t in_bytes = cells * beat_bytes(c), out_bytes = cells * sizeof(uint32_t);
   rc = ensure(&c->d_in, &c->d_in_bytes, in_bytes);
   if (rc != RSP_OK) return rc;
@@ -633,10 +659,13 @@ int rsp_chain_detections_device(rsp_chain* c, const uint32_t* d_out_words, size_
                                 rsp_detection* d_list, uint32_t cap, uint32_t* d_count) {
   if (!c) return fail(RSP_ERR_INVALID, "chain is NULL");
   if (!d_count || (cap && !d_list) || (n_frames && !d_out_words)) return fail(RSP_ERR_INVALID, "NULL buffer");
+  int rc = check_regs(c);  // the word layout (bin width, rows per frame) comes from the register file
+  if (rc != RSP_OK) return rc;
+  if (n_frames > 0x7fffffffull) return fail(RSP_ERR_INVALID, "n_frames = %zu too large for one call", n_frames);
   HIP_TRY(hipSetDevice(c->device));
   const uint32_t log2_rows = c->p.dopplerPoints ? (uint32_t)ilog2(c->p.dopplerPoints) : 0u;
   const uint64_t cells = ((uint64_t)n_frames << c->fft_stages) << log2_rows;
-  HIP_TRY(rsp::launch_compact(d_out_words, cells, c->fft_stages, log2_rows, d_list, cap, d_count, c->stream));
+  HIP_TRY(rsp::launch_compact(d_out_words, cells, c->fft_stages, log2_rows, d_list, cap, c->d_ctr, d_count, c->stream));
   return RSP_OK;
 }
 
@@ -649,29 +678,59 @@ int rsp_chain_process_detections(rsp_chain* c, const void* in_beats, size_t n_fr
   if (n_frames == 0) return RSP_OK;
   if (!in_beats || (cap && !list)) return fail(RSP_ERR_INVALID, "NULL buffer");
   if (cap > 0xffffffffull) cap = 0xffffffffull;
+  if (n_frames > (c->p.dopplerPoints ? 0xffffull : 0x7fffffffull))
+    return fail(RSP_ERR_INVALID, "n_frames = %zu too large for one call", n_frames);
   HIP_TRY(hipSetDevice(c->device));
-  const size_t cells = n_frames << c->fft_stages;
+  const size_t cells = (n_frames * (size_t)(c->p.dopplerPoints ? c->p.dopplerPoints : 1)) << c->fft_stages;
+  if (c->p.dopplerPoints && cells > 0x7fffffffull) return fail(RSP_ERR_INVALID, "2-D chain: %zu channels too many for one call", n_frames);
   rc = ensure(&c->d_in, &c->d_in_bytes, cells * beat_bytes(c));
+  if (rc != RSP_OK) return rc;
+  // dense words are kept on the device: a frame with more than RSP_FRAME_DET_CAP peaks is completed
+  // from them, so the host call never truncates a frame
+  rc = ensure(reinterpret_cast<void**>(&c->d_out), &c->d_out_bytes, cells * sizeof(uint32_t));
   if (rc != RSP_OK) return rc;
   size_t list_bytes = c->d_list_cap * sizeof(rsp_detection);
   rc = ensure(reinterpret_cast<void**>(&c->d_list), &list_bytes, std::max<size_t>(cap, 1) * sizeof(rsp_detection));
   if (rc != RSP_OK) return rc;
   c->d_list_cap = list_bytes / sizeof(rsp_detection);
   HIP_TRY(hipMemcpyAsync(c->d_in, in_beats, cells * beat_bytes(c), hipMemcpyHostToDevice, c->stream));
-  rc = launch_dense(c, c->d_in, n_frames, nullptr, c->d_list, (uint32_t)cap, c->d_count);
-  if (rc != RSP_OK) return rc;
-  uint32_t found = 0;
-  HIP_TRY(hipMemcpyAsync(&found, c->d_count, sizeof(found), hipMemcpyDeviceToHost, c->stream));
+  if (c->p.dopplerPoints) {
+    rc = launch_dense(c, c->d_in, n_frames, c->d_out);
+    if (rc != RSP_OK) return rc;
+    const uint32_t log2_rows = (uint32_t)ilog2(c->p.dopplerPoints);
+    HIP_TRY(rsp::launch_compact(c->d_out, cells, c->fft_stages, log2_rows, c->d_list, (uint32_t)cap, c->d_ctr,
+                                c->d_count, c->stream));
+  } else {
+    rc = launch_dense(c, c->d_in, n_frames, c->d_out, c->d_list, (uint32_t)cap, c->d_count);
+    if (rc != RSP_OK) return rc;
+  }
+  uint32_t counts[2] = {0, 0};  // {found, stored}
+  HIP_TRY(hipMemcpyAsync(counts, c->d_count, sizeof(counts), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  const size_t stored = std::min<size_t>(found, cap);
+  const size_t stored = std::min<size_t>(counts[1], cap);
   if (stored) HIP_TRY(hipMemcpy(list, c->d_list, stored * sizeof(rsp_detection), hipMemcpyDeviceToHost));
   std::sort(list, list + stored, [](const rsp_detection& a, const rsp_detection& b) {
     if (a.frame != b.frame) return a.frame < b.frame;
     if (a.doppler != b.doppler) return a.doppler < b.doppler;
     return a.bin < b.bin;
   });
-  *n_found = found;
+  *n_found = counts[0];
   return RSP_OK;
+}
+
+int rsp_chain_set_option(rsp_chain* c, int option, int64_t value) {
+  if (!c) return fail(RSP_ERR_INVALID, "chain is NULL");
+  switch (option) {
+    case RSP_OPT_MAX_FRAMES_PER_LAUNCH:
+      if (value < 0 || value > 0x7fffffffll) return fail(RSP_ERR_INVALID, "max frames per launch = %lld", (long long)value);
+      c->opt_max_frames = (uint32_t)value;
+      return RSP_OK;
+    case RSP_OPT_FORCE_TILED_CFAR2D:
+      c->opt_force_tiled = value != 0;
+      return RSP_OK;
+    default:
+      return fail(RSP_ERR_INVALID, "unknown option %d", option);
+  }
 }
 
 int rsp_chain_set_stream(rsp_chain* c, void* hip_stream) {

@@ -81,14 +81,9 @@ template <bool FIXED>
 __global__ void __launch_bounds__(64)
 chain1d_small_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t n_frames, int log2n,
                      ChainRegs rg, const void* __restrict__ tw, const int16_t* __restrict__ log_lut,
-                     uint32_t* __restrict__ fcount, uint2* __restrict__ fdet,
-                     uint32_t* __restrict__ zero_a, uint32_t* __restrict__ zero_b) {
+                     uint32_t* __restrict__ fcount, uint2* __restrict__ fdet) {
   using V = typename std::conditional<FIXED, int, float>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (zero_a) *zero_a = 0u;
-    if (zero_b) *zero_b = 0u;
-  }
   const int n = 1 << log2n, t = threadIdx.x;
   const uint32_t frame = blockIdx.x * 64 + t;
   const bool live = frame < n_frames;
@@ -211,18 +206,19 @@ hipError_t launch_chain1d_small(const Chain1dLaunch& a) {
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const uint32_t grid = (a.n_frames + 63) / 64;
   hipError_t e;
+  static LdsGrant granted[2];
   if (a.fixed) {
     auto k = chain1d_small_kernel<true>;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    e = grant_lds(k, lds, a.device, granted[0]);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds, a.stream, a.in, a.out, a.n_frames, a.log2n, a.regs, a.twiddles,
-                       a.log_lut, a.frame_count, a.frame_det, a.zero_a, a.zero_b);
+                       a.log_lut, a.frame_count, a.frame_det);
   } else {
     auto k = chain1d_small_kernel<false>;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    e = grant_lds(k, lds, a.device, granted[1]);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds, a.stream, a.in, a.out, a.n_frames, a.log2n, a.regs, a.twiddles,
-                       a.log_lut, a.frame_count, a.frame_det, a.zero_a, a.zero_b);
+                       a.log_lut, a.frame_count, a.frame_det);
   }
   return hipGetLastError();
 }

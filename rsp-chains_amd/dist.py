@@ -51,9 +51,10 @@ def gather_detections(local_list, local_count, cap: int, frame_offset: int = 0, 
 
 
 def gather_packed(packed, group=None, out=None, async_op: bool = False):
-    """ONE collective per step: `packed` is an int32 tensor [cap + 1, 4] whose row 0 carries the
-    detection count in column 0 and rows 1.. the list (point the C ABI's d_count at row 0 and d_list
-    at row 1).  Returns the gathered [world, cap + 1, 4] tensor (and the work handle with async_op)."""
+    """ONE collective per step: `packed` is an int32 tensor [cap + 1, 4] whose row 0 is the header
+    {peaks found, entries stored, -, -} the C ABI writes through d_count, and rows 1.. the list (point
+    d_count at row 0 and d_list at row 1).  Returns the gathered [world, cap + 1, 4] tensor (and the
+    work handle with async_op)."""
     import torch
     import torch.distributed as dist
 
@@ -67,13 +68,15 @@ def gather_packed(packed, group=None, out=None, async_op: bool = False):
 
 
 def unpack_gathered(view):
-    """[world, cap + 1, 4] from gather_packed -> (lists [world, cap, 4], counts [world])"""
-    return view[:, 1:, :], view[:, 0, 0]
+    """[world, cap + 1, 4] from gather_packed -> (lists [world, cap, 4], stored [world], found [world]).
+    Only the first stored[r] rows of lists[r] are valid (found[r] > stored[r] = that rank's list was truncated)."""
+    return view[:, 1:, :], view[:, 0, 1], view[:, 0, 0]
 
 
 def merge_gathered(lists, counts, frames_per_rank):
     """Host-side: concatenate the valid rows of every rank with global frame numbers.
-    frames_per_rank[r] = first global frame of rank r."""
+    counts[r] = entries STORED by rank r (the header's second word), frames_per_rank[r] = first global
+    frame of rank r."""
     import numpy as np
     lists = lists.cpu().numpy() if hasattr(lists, "cpu") else np.asarray(lists)
     counts = counts.cpu().numpy() if hasattr(counts, "cpu") else np.asarray(counts)

@@ -65,14 +65,19 @@ def tone_beats(n_frames, n, seed, bp=12):
     return np.stack(frames)
 
 
-def compare_f32(words, thr_ref, peak_ref, margin_ref, mag_ref=None, rtol=2e-5, min_decided=0.9, atol=0.0):
-    """fp32 device result vs float64 oracle.  Tolerance: |thr - ref| <= rtol * max(|ref|, frame
+def compare_f32(words, thr_ref, peak_ref, margin_ref, mag_ref=None, rtol=2e-5, min_decided=0.98, atol=0.0):
+    """fp32 device result vs float64 oracle.  Tolerance: |thr - ref| <= tol = rtol * max(|ref|, frame
     peak magnitude * 2^-10): the reference's own HW-vs-float acceptance is 2 LSB of a 16-bit word
-    (RspChainTesterUtils.scala:221,231) = 6e-5 of full scale; we ask for 3x tighter.  Peak flags
-    must agree wherever the oracle's decision margin exceeds that same tolerance.
+    (RspChainTesterUtils.scala:221,231) = 6e-5 of full scale; we ask for 3x tighter.
+    Peak flags: a flag is an AND of comparisons between two quantities (cut vs threshold, cut vs a
+    neighbour) that each carry at most `tol` of fp32 error, so it is compared on EVERY cell whose
+    decision margin in the oracle (orc_cfar_f64: distance of the deciding comparison from a tie)
+    exceeds 2 tol.  A cell is excluded only by its own margin; `min_decided` (>= 0.98 everywhere) is a
+    guard that the comparison stays meaningful, not a quota that hides disagreements.
     atol: log2-magnitude mode only -- fp32 rounding on near-null bins is amplified by the log, so
     that mode is held to 1 LSB (2^-9) of the reference's Q7.9 log format (FftMagCfarChain.scala:94-95)
     instead of a relative bound."""
+    assert min_decided >= 0.98
     thr, peak = R.unpack_output_f32(words)
     thr = thr.astype(np.float64).reshape(thr_ref.shape)
     peak = peak.reshape(peak_ref.shape)
@@ -81,7 +86,8 @@ def compare_f32(words, thr_ref, peak_ref, margin_ref, mag_ref=None, rtol=2e-5, m
     tol = rtol * np.maximum(np.abs(thr_ref), floor) + atol
     err = np.abs(thr - thr_ref)
     assert np.all(err <= tol), f"threshold error {np.max(err / tol):.2f} x tolerance"
-    decided = margin_ref > 4 * tol
-    assert decided.mean() > min_decided  # near-ties (|margin| within 4 tol) are not compared
-    assert np.array_equal(peak[decided], peak_ref[decided])
+    decided = margin_ref > 2 * tol
+    assert decided.mean() >= min_decided, f"only {decided.mean():.4f} of the cells have a decidable flag"
+    bad = decided & (peak != peak_ref)
+    assert not bad.any(), f"{int(bad.sum())} peak flags differ on cells with margin > 2 tol (first: {np.argwhere(bad)[0]})"
     return float(np.max(err / tol))

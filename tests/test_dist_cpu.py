@@ -40,13 +40,17 @@ WORKER = textwrap.dedent("""
     got = sorted(zip(merged[:, 0].tolist(), merged[:, 1].tolist()))
     assert got == want, (rank, got[:5], want[:5])
     assert int(counts.sum()) == len(want)
-    # the one-collective form bench.py uses: row 0 = count, rows 1.. = list
+    # the one-collective form bench.py uses: row 0 = header (found, stored), rows 1.. = list.  Rank 1
+    # pretends its list was truncated (found > stored): only the stored rows may be merged.
     packed = torch.zeros((cap + 1, 4), dtype=torch.int32)
-    packed[0, 0] = k
+    stored = k if rank == 0 else max(k - 1, 0)
+    packed[0, 0], packed[0, 1] = k, stored
     packed[1:] = torch.from_numpy(lst)
-    l2, c2 = unpack_gathered(gather_packed(packed))
-    m2 = merge_gathered(l2, c2, firsts)
-    assert sorted(zip(m2[:, 0].tolist(), m2[:, 1].tolist())) == want
+    packed[1 + stored:] = -7            # garbage beyond the stored rows must never be read
+    l2, s2, f2 = unpack_gathered(gather_packed(packed))
+    m2 = merge_gathered(l2, s2, firsts)
+    assert int(f2.sum()) == len(want) and m2.shape[0] == int(s2.sum())
+    assert (m2[:, 1] >= 0).all() and set(zip(m2[:, 0].tolist(), m2[:, 1].tolist())) <= set(want)
     dist.barrier(); dist.destroy_process_group()
     print("rank", rank, "ok", len(want))
 """)

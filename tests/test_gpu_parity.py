@@ -144,8 +144,9 @@ def test_fused_detection_list_matches_dense(gpu):
         dut.detections_device(d_out.ptr, frames, d_list2.ptr, cap, d_cnt2.ptr)
         dut.synchronize()
         dense = d_out.download(np.uint32, beats.size).reshape(frames, n)
-        found = int(d_cnt.download(np.uint32, 1)[0])
-        found2 = int(d_cnt2.download(np.uint32, 1)[0])
+        found, stored = (int(v) for v in d_cnt.download(np.uint32, 2))
+        found2, stored2 = (int(v) for v in d_cnt2.download(np.uint32, 2))
+        assert found == stored and found2 == stored2
         lst = d_list.download(np.uint32, found * 4).reshape(found, 4)
         lst2 = d_list2.download(np.uint32, found2 * 4).reshape(found2, 4)
         # list-only mode (no dense words)
@@ -159,6 +160,49 @@ def test_fused_detection_list_matches_dense(gpu):
     want = sorted(zip(fr.tolist(), bn.tolist(), dense[fr, bn].tolist()))
     for got in (lst, lst2, lst3):
         assert sorted((int(a), int(b), int(w)) for a, b, _, w in got) == want
+
+
+def test_detection_list_is_complete_beyond_the_per_frame_staging(gpu):
+    """Frames with far more than RSP_FRAME_DET_CAP = 64 peaks (Smallest Of, scaler 0.75 on noise: hundreds
+    per frame).  The reference emits every peak (Tester:145-167), so: the host call and the fused
+    device call WITH dense words return every one of them; the list-only device call keeps at most 64
+    per frame and says so through d_count = {found, stored}."""
+    n, frames = 1024, 300                                   # 300 frames: two compaction workgroups
+    params = make_params(n)
+    rt = R.RunTimeRspChainParams(CFARMode="Smallest Of", thresholdScaler=0.75)
+    beats = random_beats(frames, n, 4711, amp=3000)
+    beats[5] = tone_beats(1, n, 5)[0]                       # one ordinary frame in between
+    ref = O.chain_fixed(beats, oracle_cfg(params, rt)).reshape(frames, n)
+    fr, bn = np.nonzero(ref & 1)
+    per_frame = np.bincount(fr, minlength=frames)
+    assert per_frame.max() > 200 and per_frame.min() < 64
+    want = sorted(zip(fr.tolist(), bn.tolist(), ref[fr, bn].tolist()))
+    cap = 1 << 18
+    with R.FftMagCfarChainVanilla(params) as dut:
+        dut.configure(rt)
+        det, found = dut.detections(beats, cap=cap)
+        assert found == fr.size == det.size
+        assert np.array_equal(det["frame"], fr) and np.array_equal(det["bin"], bn) and np.array_equal(det["word"], ref[fr, bn])
+        small, found_small = dut.detections(beats, cap=1000)   # cap smaller than the list: truncated, no garbage
+        assert found_small == fr.size and small.size == 1000
+        assert set(zip(small["frame"].tolist(), small["bin"].tolist())) <= set(zip(fr.tolist(), bn.tolist()))
+        d_in = R.DeviceBuffer(beats.nbytes); d_in.upload(beats)
+        d_out = R.DeviceBuffer(beats.size * 4)
+        d_list, d_cnt = R.DeviceBuffer(cap * 16), R.DeviceBuffer(8)
+        dut.process_detect_device(d_in.ptr, frames, d_out.ptr, d_list.ptr, cap, d_cnt.ptr)
+        dut.synchronize()
+        cnt = d_cnt.download(np.uint32, 2)
+        assert cnt[0] == fr.size and cnt[1] == fr.size
+        lst = d_list.download(np.uint32, int(cnt[1]) * 4).reshape(-1, 4)
+        assert sorted((int(a), int(b), int(w)) for a, b, _, w in lst) == want
+        dut.process_detect_device(d_in.ptr, frames, 0, d_list.ptr, cap, d_cnt.ptr)   # list only
+        dut.synchronize()
+        cnt = d_cnt.download(np.uint32, 2)
+        assert cnt[0] == fr.size and cnt[1] == np.minimum(per_frame, 64).sum()
+        lst = d_list.download(np.uint32, int(cnt[1]) * 4).reshape(-1, 4)
+        got = set((int(a), int(b), int(w)) for a, b, _, w in lst)
+        assert len(got) == cnt[1] and got <= set(want)
+        assert np.array_equal(np.bincount(lst[:, 0], minlength=frames), np.minimum(per_frame, 64))
 
 
 @pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, 8192])
@@ -304,7 +348,7 @@ def test_cash_register_only_exists_with_includeCASH(gpu):
             dut.check()
 
 
-def test_chunked_launch_path(gpu, monkeypatch):
+def test_chunked_launch_path(gpu):
     """Launches whose input would exceed 4 GiB are split (kernels use 32-bit byte offsets).  Force the
     split at 64 frames and check dense words and the fused detection list are unchanged."""
     n, frames = 1024, 200
@@ -312,9 +356,9 @@ def test_chunked_launch_path(gpu, monkeypatch):
     rt = R.RunTimeRspChainParams()
     beats = np.concatenate([tone_beats(8, n, 71), random_beats(frames - 8, n, 72)])
     ref = O.chain_fixed(beats, oracle_cfg(params, rt)).reshape(frames, n)
-    monkeypatch.setenv("RSP_DEBUG_MAX_FRAMES", "64")
     with R.FftMagCfarChainVanilla(params) as dut:
         dut.configure(rt)
+        dut.set_option(dut.MAX_FRAMES_PER_LAUNCH, 50)     # rounded up to whole 64-frame pieces
         assert np.array_equal(dut.stream(beats), ref)
         det, found = dut.detections(beats)
     fr, bn = np.nonzero(ref & 1)
@@ -360,5 +404,5 @@ def test_small_runtime_fft_sizes(gpu, n):
         words = dut.stream(x)
         det, found = dut.detections(x)
     thr, peak, margin, mag = O.chain_f32(x, oracle_fcfg(paramsf, rt), want_mag=True)
-    compare_f32(words, thr, peak, margin, mag, min_decided=0.8)
+    compare_f32(words, thr, peak, margin, mag)
     assert found == int((words & 1).sum())
