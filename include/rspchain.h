@@ -202,7 +202,8 @@ int rsp_chain_process_detections(rsp_chain* c, const void* in_beats, size_t n_fr
 /* Tuning / test knobs (no reference counterpart; replaces environment variables of round 1). */
 enum {
   RSP_OPT_MAX_FRAMES_PER_LAUNCH = 1, /* split a call into launches of at most this many frames (0 = automatic) */
-  RSP_OPT_FORCE_TILED_CFAR2D = 2     /* 2-D chain: run-time-window CFAR kernel even for the compile-time windows */
+  RSP_OPT_FORCE_TILED_CFAR2D = 2,    /* 2-D chain: run-time-window CFAR kernel even for the compile-time windows */
+  RSP_OPT_FORCE_GENERIC_TAIL = 3     /* 1-D chain: per-cell CFAR tail even where the 16-byte "quad" tail applies */
 };
 int rsp_chain_set_option(rsp_chain* c, int option, int64_t value);
 

@@ -29,6 +29,22 @@ namespace rsp {
 #define ABL(bit) false
 #endif
 
+// -DRSP_STAMP builds (tools/stamp.sh): s_memtime at the phase boundaries of a few workgroups, printed
+// by one wave each -- where a workgroup's lifetime goes while the chip is loaded.  Production builds
+// compile it away.
+#ifdef RSP_STAMP
+__device__ uint64_t g_stamp[16];  // per-thread copy would cost VGPRs; stamps are wave-uniform SGPR values
+#define STAMP_DECL uint64_t st_[12] = {}
+#define STAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); st_[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP_ARG , st_
+#define STAMP_PARAM , uint64_t (&st_)[12]
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_ARG
+#define STAMP_PARAM
+#endif
+
 // ---------------------------------------------------------------- LDS layout per frame
 // After the FFT the frame's LDS is re-used for the CFAR working set (4-byte slots):
 //   mag : cell x in [-16, N+16)   at slot pad(x + 16)    (1-cell halo for peak grouping)
@@ -42,10 +58,10 @@ constexpr int kHalo = 256;  // >= refWindow + guardWindow + 1 (checked on the ho
 template <int M>
 struct FrameLds {
   static constexpr int N = 1 << M;
-  static constexpr int PADN = pad_slots(N);
+  static constexpr int PADN = fft_image_slots(M);
   static constexpr int MAG_SLOTS = pad_slots(N + 32) + 1;
   static constexpr int PB_SLOTS = pad_slots(N + 2 * kHalo) + 2;
-  static constexpr int BS_SLOTS = N / 256 + 2;
+  static constexpr int BS_SLOTS = N / 256 + 3;  // blocks -1 .. N/256, + one slot that holds 0
   static constexpr int MAG_OFF = 0;
   static constexpr int PB_OFF = MAG_OFF + 4 * MAG_SLOTS;
   static constexpr int BS_OFF = PB_OFF + 4 * PB_SLOTS;
@@ -165,12 +181,14 @@ __device__ __forceinline__ void front_end(const void* __restrict__ in, uint32_t 
                                           unsigned char* fbase, const ChainRegs& rg,
                                           const void* __restrict__ tw,
                                           const int16_t* __restrict__ log_lut, uint32_t* rom,
-                                          V (&mg)[16]) {
+                                          V (&mg)[16] STAMP_PARAM) {
   constexpr int N = 1 << M, NP = plan_np(M);
   if constexpr (!FIXED) {
     f32x2* buf = reinterpret_cast<f32x2*>(fbase);
     const f32x2* twf = reinterpret_cast<const f32x2*>(tw);
     f32x2 x[16];
+    TwAll<M> twb;
+    twb.load(tau, twf);
     {
       constexpr int W = plan_w(M, 0), LO = plan_lo(M, 0);
       // uniform base (SGPR pair) + one 32-bit per-thread byte offset; the per-register part is a
@@ -184,45 +202,76 @@ __device__ __forceinline__ void front_end(const void* __restrict__ in, uint32_t 
         x[e] = *reinterpret_cast<const f32x2*>(gbase + (size_t)voff + eo);
       }
     }
-    if (!ABL(0)) pass_f32<M, 0>(x, tau, twf);
+    STAMP(1);
+    if (!ABL(0)) pass_f32<M, 0>(x, twb.template get<0>());
+    STAMP(2);
     // passes 1..NP-1 through LDS
     auto exchange = [&](auto pc) {
       constexpr int P = decltype(pc)::value;
       constexpr int W0 = plan_w(M, P - 1), LO0 = plan_lo(M, P - 1);
       constexpr int W1 = plan_w(M, P), LO1 = plan_lo(M, P);
+      constexpr bool LAST = P == NP - 1;
       if (!ABL(3)) {
 #pragma unroll
       for (int g = 0; g < (16 >> W0); ++g) {
-        f32x2* b0 = buf + slot_base<M, LO0, W0>(tau, g);
+        f32x2* b0 = buf + slot_base<M, LO0, W0, LAST>(tau, g);
 #pragma unroll
-        for (int r = 0; r < (1 << W0); ++r) b0[slot_delta<LO0, W0>(r)] = x[g * (1 << W0) + r];
+        for (int r = 0; r < (1 << W0); ++r) b0[slot_delta<M, LO0, W0>(r)] = x[g * (1 << W0) + r];
       }
       }
       __syncthreads();
       if (!ABL(3)) {
 #pragma unroll
       for (int g = 0; g < (16 >> W1); ++g) {
-        const f32x2* b1 = buf + slot_base<M, LO1, W1>(tau, g);
+        const f32x2* b1 = buf + slot_base<M, LO1, W1, LAST>(tau, g);
 #pragma unroll
-        for (int r = 0; r < (1 << W1); ++r) x[g * (1 << W1) + r] = b1[slot_delta<LO1, W1>(r)];
+        for (int r = 0; r < (1 << W1); ++r) x[g * (1 << W1) + r] = b1[slot_delta<M, LO1, W1>(r)];
       }
       }
-      if (!ABL(0)) pass_f32<M, P>(x, tau, twf);
+      STAMP(2 * P + 1);
+      if (!ABL(0)) pass_f32<M, P>(x, twb.template get<P>());
+      STAMP(2 * P + 2);
     };
     exchange(std::integral_constant<int, 1>{});
     if constexpr (NP > 2) exchange(std::integral_constant<int, 2>{});
     if constexpr (NP > 3) exchange(std::integral_constant<int, 3>{});
     const float scale = 1.0f / (float)N;  // net 1/N: FftMagCfarChainTester.scala:77
-    // mode select hoisted out of the per-bin loop (a uniform branch per bin costs ~15 SALU each)
+    // mode select hoisted out of the per-bin loop (a uniform branch per bin costs ~15 SALU each).
+    // JPL and squared magnitude are homogeneous, so the power-of-two 1/N scale is applied to the
+    // magnitude (bit-identical to scaling the spectrum first) and two bins share every packed op.
+    auto jpl_pairs = [&]() {
+      const f32x2 k8 = {0.125f, 0.125f}, k78 = {0.875f, 0.875f}, k2 = {0.5f, 0.5f}, ss = {scale, scale};
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) {
+        const f32x2 a = x[e], b = x[e + 1];
+        const f32x2 uu = {fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(b.x), fabsf(b.y))};
+        const f32x2 vv = {fminf(fabsf(a.x), fabsf(a.y)), fminf(fabsf(b.x), fabsf(b.y))};
+        const f32x2 t1 = __builtin_elementwise_fma(vv, k8, uu);
+        const f32x2 t2 = __builtin_elementwise_fma(uu, k78, vv * k2);
+        const f32x2 m = f32x2{fmaxf(t1.x, t2.x), fmaxf(t1.y, t2.y)} * ss;
+        mg[e] = m.x;
+        mg[e + 1] = m.y;
+      }
+    };
+#ifdef RSP_COUNT_PATH
+    if (true) jpl_pairs();
+    else
+#endif
     if (ABL(4)) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) mg[e] = x[e].x;
     } else if (rg.mag_mode == 2) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) mg[e] = mag_f32(x[e] * scale, 2);
+      jpl_pairs();
     } else if (rg.mag_mode == 0) {
+      const f32x2 s2 = {scale * scale, scale * scale};
 #pragma unroll
-      for (int e = 0; e < 16; ++e) mg[e] = mag_f32(x[e] * scale, 0);
+      for (int e = 0; e < 16; e += 2) {
+        const f32x2 a = x[e], b = x[e + 1];
+        const f32x2 re = {a.x, b.x}, im = {a.y, b.y};
+        const f32x2 m = __builtin_elementwise_fma(im, im, re * re) * s2;
+        mg[e] = m.x;
+        mg[e + 1] = m.y;
+      }
     } else {
 #pragma unroll
       for (int e = 0; e < 16; ++e) mg[e] = mag_f32(x[e] * scale, 1);
@@ -254,22 +303,23 @@ __device__ __forceinline__ void front_end(const void* __restrict__ in, uint32_t 
         constexpr int P = decltype(pc)::value;
         constexpr int W0 = plan_w(M, P - 1), LO0 = plan_lo(M, P - 1);
         constexpr int W1 = plan_w(M, P), LO1 = plan_lo(M, P);
+        constexpr bool LAST = P == NP - 1;
 #pragma unroll
         for (int g = 0; g < (16 >> W0); ++g) {
-          uint32_t* b0 = buf + slot_base<M, LO0, W0>(tau, g);
+          uint32_t* b0 = buf + slot_base<M, LO0, W0, LAST>(tau, g);
 #pragma unroll
           for (int r = 0; r < (1 << W0); ++r) {
             const int e = g * (1 << W0) + r;
-            b0[slot_delta<LO0, W0>(r)] = ((uint32_t)xr[e] << 16) | ((uint32_t)xi[e] & 0xffffu);
+            b0[slot_delta<M, LO0, W0>(r)] = ((uint32_t)xr[e] << 16) | ((uint32_t)xi[e] & 0xffffu);
           }
         }
         __syncthreads();
 #pragma unroll
         for (int g = 0; g < (16 >> W1); ++g) {
-          const uint32_t* b1 = buf + slot_base<M, LO1, W1>(tau, g);
+          const uint32_t* b1 = buf + slot_base<M, LO1, W1, LAST>(tau, g);
 #pragma unroll
           for (int r = 0; r < (1 << W1); ++r) {
-            const uint32_t b = b1[slot_delta<LO1, W1>(r)];
+            const uint32_t b = b1[slot_delta<M, LO1, W1>(r)];
             xr[g * (1 << W1) + r] = (int)(short)(b >> 16);
             xi[g * (1 << W1) + r] = (int)(short)(b & 0xffffu);
           }
@@ -294,17 +344,20 @@ __device__ __forceinline__ void front_end(const void* __restrict__ in, uint32_t 
 
 }
 
-// magnitudes -> LDS in natural bin order, cell x at slot pad(x + moff) (moff a multiple of 16)
-template <int M, typename V>
+// magnitudes -> LDS in natural bin order, cell x at slot x' + PM (x' >> 4), x' = x + moff (moff a multiple
+// of 16): PM = 1 is the FFT image's padding, PM = 4 the 16-byte-aligned one of the quad tail
+template <int M, typename V, int PM = 1>
 __device__ __forceinline__ void write_mag(V* mag, int moff, int tau, const V (&mg)[16]) {
   constexpr int T = threads_per_frame(M), NP = plan_np(M), WL = plan_w(M, NP - 1);
 #pragma unroll
   for (int g = 0; g < (16 >> WL); ++g) {
-    // bin = (q << (M-WL)) | bitrev(c): q << (M-WL) is a multiple of 16, so its slot offset is constant
-    V* mb = mag + pad((int)(__brev((unsigned)(g * T + tau)) >> (32 - (M - WL))) + moff);
+    // bin = (q << (M-WL)) | (g T + tau) (fft_lds.hpp, last pass): q << (M-WL) is a multiple of 16, so its
+    // slot offset is constant, and consecutive lanes write consecutive slots
+    const int x = g * T + tau + moff;
+    V* mb = mag + x + PM * (x >> 4);
 #pragma unroll
     for (int p = 0; p < (1 << WL); ++p) {
-      constexpr int QS = (1 << (M - WL)) + (1 << (M - WL - 4));
+      constexpr int QS = (1 << (M - WL)) + PM * (1 << (M - WL - 4));
       mb[bitrev_c(p, WL) * QS] = mg[g * (1 << WL) + p];
     }
   }
@@ -324,7 +377,11 @@ __device__ __forceinline__ void emit_words(const uint32_t (&word)[16], uint32_t*
     for (int j = 0; j < 16; ++j)
       *reinterpret_cast<uint32_t*>(obase + (size_t)ooff + (size_t)(T * j) * 4u) = word[j];
   }
+#ifdef RSP_COUNT_PATH
+  if (false) {
+#else
   if (fcount) {
+#endif
     uint32_t hits = 0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) hits |= (word[j] & 1u) << j;
@@ -365,8 +422,9 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
   unsigned char* fbase = smem + fl * L::BYTES;
 
   V mg[16];
+  STAMP_DECL;
   front_end<M, FIXED, V>(in, frame, live, tau, fbase, rg, tw, log_lut,
-                         reinterpret_cast<uint32_t*>(smem + (size_t)L::BYTES * FPW), mg);
+                         reinterpret_cast<uint32_t*>(smem + (size_t)L::BYTES * FPW), mg STAMP_ARG);
 
   // ---- magnitudes to LDS in natural bin order ----
   V* mag = reinterpret_cast<V*>(fbase + L::MAG_OFF);
@@ -523,6 +581,10 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
     using I3 = std::integral_constant<int, 3>;
+#ifdef RSP_COUNT_PATH
+    if (true) cells(I0{}, std::false_type{});
+    else
+#endif
     if (ABL(1)) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) word[j] = __builtin_bit_cast(uint32_t, pm[JS * j]);
@@ -539,6 +601,376 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
     }
   }
   emit_words<M>(word, out, frame, live, tau, det_cnt, det_stage, fcount, fdet);
+}
+
+// ---------------------------------------------------------------- quad tail (the default CA/GO/SO path)
+// Same front end; the CFAR stage works on QUADS of 4 consecutive cells so that every LDS access of
+// the tail is one conflict-free 16-byte ds_read/ds_write_b128 on UNPADDED images and every word store
+// one 16-byte global store (1 KiB per wave-instruction).  Thread tau owns quads tau + T e, e = 0..3
+// (cells 4 tau + 4 T e + i) for BOTH the prefix scan and the cells, so a quad's magnitudes are read
+// from LDS once and stay in registers:
+//   scan   in-quad prefix (3 adds), then an inclusive DPP scan of the quad totals over the wave: for a
+//          fixed e the 64 lanes of a wave hold 64 consecutive quads = one 256-cell block, so the
+//          block-relative prefix needs no cross-wave step and no second level;
+//   cells  6 quad reads (4 prefixes, 2 magnitudes), 1 quad store.
+// A window sum needs the exclusive prefix P at two positions.  With refWindow and guardWindow
+// multiples of 4 the lagging positions k - G - R, k - G are quad-aligned; the leading ones
+// k + G + 1, k + G + R + 1 are off by one, so that side uses P[x + 1] = P[x] + m[x] at the aligned
+// x = k + G, k + G + R (two more quad reads of the magnitudes, no second prefix array).
+constexpr int kQHalo = 144;  // magnitude cells kept right of the frame: >= R + G + 4, a multiple of 16
+
+template <int M>
+struct QuadLds {
+  static constexpr int N = 1 << M;
+  static constexpr int MAG_SLOTS = 16 + N + kQHalo;  // cell x in [-16, N + kQHalo) at x + 16
+  static constexpr int PB_SLOTS = N + 2 * kHalo;     // cell x in [-256, N + 256) at x + 256
+  static constexpr int BS_SLOTS = N / 256 + 3;       // blocks -1 .. N/256, + one slot that holds 0
+  static constexpr int MAG_OFF = 0;
+  static constexpr int PB_OFF = MAG_OFF + 4 * MAG_SLOTS;
+  static constexpr int BS_OFF = PB_OFF + 4 * PB_SLOTS;
+  static constexpr int DET_OFF = (BS_OFF + 4 * BS_SLOTS + 7) & ~7;
+  static constexpr int CFAR_BYTES = DET_OFF + 8 + 8 * kFrameDetCap;
+  static constexpr int FFT_BYTES = 8 * fft_image_slots(M);
+  static constexpr int BYTES = ((CFAR_BYTES > FFT_BYTES ? CFAR_BYTES : FFT_BYTES) + 15) & ~15;
+  static constexpr int ROM_BYTES = 4 * (N / 2);
+};
+
+template <typename V> struct Vec4;
+template <> struct Vec4<float> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct Vec4<int> { typedef int type __attribute__((ext_vector_type(4))); };
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// the geometry the quad tail is built for (host-side dispatch, launch_m)
+__host__ __device__ inline bool quad_tail_supports(int log2n, const ChainRegs& rg) {
+  (void)log2n;
+  return rg.algorithm == 0 && rg.cfar_mode <= 2 && (rg.R & 3) == 0 && (rg.G & 3) == 0 && rg.R + rg.G + 4 <= kQHalo;
+}
+
+template <int CTRL, int RMASK, bool BOUND, typename V>
+__device__ __forceinline__ V dpp_v(V v) {
+  static_assert(sizeof(V) == 4, "32-bit lanes");
+  return __builtin_bit_cast(V, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, RMASK, 0xf, BOUND));
+}
+// v += (lane 15 of the previous row -> rows 1 and 3) / (lane 31 -> rows 2 and 3): ONE v_add_*_dpp whose
+// disabled rows keep their value.  Written as inline asm because the compiler does not fold the masked
+// broadcast into the add (it emits v_mov 0 + v_mov_dpp + v_add); the s_nop covers the 2 wait states a DPP
+// read needs after a VALU write of the same register, which the compiler does not insert for asm.
+template <int BCAST, typename V>
+__device__ __forceinline__ V row_bcast_add(V v) {
+  static_assert(BCAST == 15 || BCAST == 31, "row_bcast:15 / row_bcast:31");
+  if constexpr (std::is_same<V, float>::value) {
+    if constexpr (BCAST == 15) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa" : "+v"(v));
+    else asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc" : "+v"(v));
+  } else {
+    if constexpr (BCAST == 15) asm volatile("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa" : "+v"(v));
+    else asm volatile("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc" : "+v"(v));
+  }
+  return v;
+}
+// inclusive scan over aligned segments of WD = 16, 32 or 64 lanes
+template <int WD, typename V>
+__device__ __forceinline__ V seg_scan(V v) {
+  v += dpp_v<0x111, 0xf, true>(v);  // row_shr:1,2,4,8: inclusive scan of each 16-lane row
+  v += dpp_v<0x112, 0xf, true>(v);
+  v += dpp_v<0x114, 0xf, true>(v);
+  v += dpp_v<0x118, 0xf, true>(v);
+  if constexpr (WD >= 32) v = row_bcast_add<15>(v);
+  if constexpr (WD >= 64) v = row_bcast_add<31>(v);
+  return v;
+}
+
+template <int M, bool FIXED>
+__global__ void __launch_bounds__(wg_size(M))
+chain1d_quad_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t n_frames,
+                    ChainRegs rg, const void* __restrict__ tw, const int16_t* __restrict__ log_lut,
+                    uint32_t* __restrict__ fcount, uint2* __restrict__ fdet) {
+  constexpr int N = 1 << M, T = threads_per_frame(M), FPW = frames_per_wg(M);
+  constexpr int WD = T < 64 ? T : 64;  // lanes of a wave that belong to one frame
+  constexpr int SPB = 64 / WD;         // lane segments (values of e) per 256-cell block
+  using L = QuadLds<M>;
+  using V = typename std::conditional<FIXED, int, float>::type;
+  using V4 = typename Vec4<V>::type;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int fl = tid / T, tau = tid % T;
+  const uint32_t frame = blockIdx.x * FPW + fl;
+  const bool live = frame < n_frames;  // dead frames still walk every barrier
+  unsigned char* fbase = smem + fl * L::BYTES;
+
+  V mg[16];
+  STAMP_DECL;
+  STAMP(0);
+  front_end<M, FIXED, V>(in, frame, live, tau, fbase, rg, tw, log_lut,
+                         reinterpret_cast<uint32_t*>(smem + (size_t)L::BYTES * FPW), mg STAMP_ARG);
+  STAMP(7);
+
+  V* mag = reinterpret_cast<V*>(fbase + L::MAG_OFF) + 16;   // mag[x], x in [-16, N + kQHalo)
+  V* pb = reinterpret_cast<V*>(fbase + L::PB_OFF) + kHalo;  // pb[x], x in [-256, N + 256)
+  V* bs = reinterpret_cast<V*>(fbase + L::BS_OFF) + 1;      // bs[-1] .. bs[N/256], bs[N/256 + 1] = 0
+  uint32_t* det_cnt = reinterpret_cast<uint32_t*>(fbase + L::DET_OFF);
+  uint2* det_stage = reinterpret_cast<uint2*>(fbase + L::DET_OFF + 8);
+  const bool wrap = rg.edge != 0;
+  __syncthreads();  // every thread is done reading the FFT image this overlays
+  {  // magnitudes to LDS in natural bin order: register (g, p) holds bin (bitrev(p) << (M - WL)) | (g T + tau)
+    constexpr int NP = plan_np(M), WL = plan_w(M, NP - 1);
+#pragma unroll
+    for (int g = 0; g < (16 >> WL); ++g) {
+      V* mb = mag + g * T + tau;
+#pragma unroll
+      for (int p = 0; p < (1 << WL); ++p) mb[bitrev_c(p, WL) << (M - WL)] = mg[g * (1 << WL) + p];
+    }
+  }
+  if (tau == 0) {
+    *det_cnt = 0u;
+    bs[N / 256 + 1] = V(0);  // the "no block total" slot of the window fix-ups
+  }
+  __syncthreads();
+  STAMP(8);
+
+  // ---- scan: block-relative exclusive prefix sums of the thread's 4 quads ----
+  V4 mq[4];
+  {
+    const V4 zero4 = {V(0), V(0), V(0), V(0)};
+    V inc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mq[e] = *reinterpret_cast<const V4*>(mag + 4 * (tau + T * e));
+    V p1[4], p2[4], p3[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      p1[e] = mq[e][0];
+      p2[e] = p1[e] + mq[e][1];
+      p3[e] = p2[e] + mq[e][2];
+      inc[e] = seg_scan<WD, V>(p3[e] + mq[e][3]);
+    }
+    V tot[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int q = tau + T * e;  // quad index; block q >> 6, position q & 63
+      tot[e] = inc[e];            // inclusive through this quad, within the lane segment
+      V exc = inc[e] - (p3[e] + mq[e][3]);
+      if constexpr (SPB > 1) {    // a block spans SPB values of e (frames of 256 / 512 points): carry the earlier ones
+        V carry = V(0);
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+          if (e2 < e && e2 >= e - e % SPB)
+            carry += __builtin_bit_cast(V, __shfl(__builtin_bit_cast(int, inc[e2]), (threadIdx.x & 63 & ~(WD - 1)) | (WD - 1)));
+        }
+        exc += carry;
+        tot[e] += carry;
+      }
+      const V4 pq = V4{V(0), p1[e], p2[e], p3[e]} + exc;
+      *reinterpret_cast<V4*>(pb + 4 * q) = pq;
+      // halos: zeros, or the wrapped image of the first / last block (prefixes), of the first kQHalo
+      // cells (magnitudes right of the frame) and of the last cell (left neighbour of cell 0)
+      if (q < 64) {
+        *reinterpret_cast<V4*>(pb + 4 * q + N) = wrap ? pq : zero4;
+        if (q < kQHalo / 4) *reinterpret_cast<V4*>(mag + 4 * q + N) = wrap ? mq[e] : zero4;
+      }
+      if (q >= N / 4 - 64) *reinterpret_cast<V4*>(pb + 4 * q - N) = wrap ? pq : zero4;
+      if (q == N / 4 - 1) mag[-1] = wrap ? mq[e][3] : V(0);
+    }
+    // block totals: the lane that holds a block's last quad (for T >= 64 the same lane for every e)
+    auto block_total = [&](int e) {
+      const int blk = (tau + T * e) >> 6;
+      bs[blk] = tot[e];
+      if (blk == N / 256 - 1) bs[-1] = wrap ? tot[e] : V(0);
+      if (blk == 0) bs[N / 256] = wrap ? tot[e] : V(0);
+    };
+    if constexpr (T % 64 == 0) {
+      if ((tau & 63) == 63) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) block_total(e);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (((tau + T * e) & 63) == 63) block_total(e);
+    }
+  }
+  __syncthreads();
+
+  STAMP(9);
+  // ---- CFAR on quads: cells k0 + i, k0 = 4 tau + 4 T e, i = 0..3 ----
+  uint32_t word[16];
+  {
+    const int R = rg.R, G = rg.G;
+    const int k00 = 4 * tau;
+    const V* pa = pb + (k00 - G);       // P[k - G]        lagging end
+    const V* pbq = pb + (k00 - G - R);  // P[k - G - R]    lagging start
+    const V* pe = pb + (k00 + G + R);   // P[k + G + R]    + m = P[k + G + R + 1] leading end
+    const V* ps = pb + (k00 + G);       // P[k + G]        + m = P[k + G + 1]     leading start
+    const V* me = mag + (k00 + G + R);
+    const V* ms = mag + (k00 + G);
+    const V* mc = mag + k00;
+    constexpr int ES = 4 * T;  // cells between a thread's consecutive quads
+    const float kA = rg.linear ? rg.div_f * rg.scaler_f : rg.div_f, kB = rg.linear ? 0.0f : rg.scaler_f;
+    // block (256 cells) of the two window starts, and whether the window ends in the next block: then
+    // the start block's total is added.  A quad never straddles a block, so this is per quad; the
+    // "no" case reads the slot that holds 0, which keeps the read unconditional (no divergent branch).
+    constexpr int ZS = N / 256 + 1;
+    auto cells = [&](auto mode_c, auto group_c) {
+      constexpr int MODE = decltype(mode_c)::value;
+      constexpr bool GROUP = decltype(group_c)::value;
+      int i0[4], i1[4];
+      if constexpr ((4 * T) % 256 == 0) {  // a thread's quads sit whole blocks apart: same case for all four
+        const int bu0 = (k00 - G - R) >> 8, bu1 = (k00 + G) >> 8;
+        const bool z0 = ((k00 - G) >> 8) == bu0, z1 = ((k00 + G + R) >> 8) == bu1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          i0[e] = z0 ? ZS : bu0 + (4 * T / 256) * e;
+          i1[e] = z1 ? ZS : bu1 + (4 * T / 256) * e;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k0 = k00 + 4 * T * e;
+          const int bu0 = (k0 - G - R) >> 8, bu1 = (k0 + G) >> 8;
+          i0[e] = ((k0 - G) >> 8) != bu0 ? bu0 : ZS;
+          i1[e] = ((k0 + G + R) >> 8) != bu1 ? bu1 : ZS;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k0 = k00 + 4 * T * e;
+        const V4 Pa = *reinterpret_cast<const V4*>(pa + ES * e), Pb = *reinterpret_cast<const V4*>(pbq + ES * e);
+        const V4 Pe = *reinterpret_cast<const V4*>(pe + ES * e), Ps = *reinterpret_cast<const V4*>(ps + ES * e);
+        const V4 Me = *reinterpret_cast<const V4*>(me + ES * e), Ms = *reinterpret_cast<const V4*>(ms + ES * e);
+        const V4 cut = mq[e];
+        const V f0 = bs[i0[e]], f1 = bs[i1[e]];
+        V nl = V(0), nr = V(0);
+        if constexpr (GROUP) {
+          nl = mc[ES * e - 1];
+          nr = mc[ES * e + 4];
+        }
+        if constexpr (!FIXED) {
+          // two cells per packed op: sums, combination and threshold of a quad in 14-16 v_pk ops
+          const f32x2 kAA = {MODE == 0 ? kA * 0.5f : kA, MODE == 0 ? kA * 0.5f : kA}, kBB = {kB, kB};
+          const f32x2 f00 = {f0, f0}, f11 = {f1, f1}, f01 = {f0 + f1, f0 + f1};
+          auto half = [&](auto hc) {
+            constexpr int h = decltype(hc)::value;
+            const f32x2 a = __builtin_shufflevector(Pa, Pa, 2 * h, 2 * h + 1), b = __builtin_shufflevector(Pb, Pb, 2 * h, 2 * h + 1);
+            const f32x2 pe2 = __builtin_shufflevector(Pe, Pe, 2 * h, 2 * h + 1), ps2 = __builtin_shufflevector(Ps, Ps, 2 * h, 2 * h + 1);
+            const f32x2 me2 = __builtin_shufflevector(Me, Me, 2 * h, 2 * h + 1), ms2 = __builtin_shufflevector(Ms, Ms, 2 * h, 2 * h + 1);
+            const f32x2 c2 = __builtin_shufflevector(cut, cut, 2 * h, 2 * h + 1);
+            const f32x2 lag = a - b;
+            const f32x2 lead = (pe2 - ps2) + (me2 - ms2);
+            f32x2 thr2;
+            if constexpr (MODE == 0) {
+              thr2 = __builtin_elementwise_fma((lag + lead) + f01, kAA, kBB);
+            } else {
+              const f32x2 lg = lag + f00, ld = lead + f11;
+              const f32x2 comb = {MODE == 1 ? fmaxf(lg.x, ld.x) : fminf(lg.x, ld.x),
+                                  MODE == 1 ? fmaxf(lg.y, ld.y) : fminf(lg.y, ld.y)};
+              thr2 = __builtin_elementwise_fma(comb, kAA, kBB);
+            }
+            if constexpr (!GROUP) {
+              // cut > thr  <=>  thr - cut < 0: the sign bit of the (correctly rounded, never flushed: both
+              // operands are normal and differ by >= 1 ulp) difference IS the peak flag
+              const f32x2 d = thr2 - c2;
+              word[4 * e + 2 * h] = (__float_as_uint(thr2.x) & ~1u) | (__float_as_uint(d.x) >> 31);
+              word[4 * e + 2 * h + 1] = (__float_as_uint(thr2.y) & ~1u) | (__float_as_uint(d.y) >> 31);
+            } else {
+#pragma unroll
+              for (int u = 0; u < 2; ++u) {
+                const int i = 2 * h + u;
+                const bool group_ok = cut[i] > (i == 0 ? nl : cut[i - 1]) && cut[i] > (i == 3 ? nr : cut[i + 1]);
+                const float thr = thr2[u];
+                const uint32_t peak = (cut[i] > thr) && group_ok;
+                word[4 * e + i] = (__float_as_uint(thr) & ~1u) | peak;
+              }
+            }
+          };
+          half(std::integral_constant<int, 0>{});
+          half(std::integral_constant<int, 1>{});
+        } else {
+          const V4 lag = (Pa - Pb) + f0;
+          const V4 lead = ((Pe - Ps) + (Me - Ms)) + f1;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            bool group_ok = true;
+            if constexpr (GROUP) group_ok = cut[i] > (i == 0 ? nl : cut[i - 1]) && cut[i] > (i == 3 ? nr : cut[i + 1]);
+            const V sl = CfarMath<V>::side(lag[i], rg), sd = CfarMath<V>::side(lead[i], rg);
+            V stat;
+            if constexpr (MODE == 0) stat = CfarMath<V>::half_sum(sl, sd);
+            else if constexpr (MODE == 1) stat = sl > sd ? sl : sd;
+            else stat = sl < sd ? sl : sd;
+            word[4 * e + i] = CfarMath<V>::finish(stat, cut[i], group_ok, k0 + i, M, rg);
+#ifdef RSP_DBG_OUT  // debugging side builds only: expose the tail's inputs instead of the words
+            word[4 * e + i] = (uint32_t)(RSP_DBG_OUT == 1 ? cut[i] : RSP_DBG_OUT == 2 ? Pa[i] : RSP_DBG_OUT == 3 ? Me[i] : Pe[i]);
+#endif
+          }
+        }
+      }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+#ifdef RSP_COUNT_PATH  // static instruction counts of ONE path (tools/count_insts.sh): CA, no grouping
+    cells(I0{}, std::false_type{});
+#else
+    if (rg.peak_grouping) {
+      if (rg.cfar_mode == 0) cells(I0{}, std::true_type{});
+      else if (rg.cfar_mode == 1) cells(I1{}, std::true_type{});
+      else cells(I2{}, std::true_type{});
+    } else {
+      if (rg.cfar_mode == 0) cells(I0{}, std::false_type{});
+      else if (rg.cfar_mode == 1) cells(I1{}, std::false_type{});
+      else cells(I2{}, std::false_type{});
+    }
+#endif
+  }
+
+  STAMP(10);
+  // ---- dense words: one 16-byte store per quad (1 KiB per wave-instruction) ----
+  if (live && out) {
+    char* obase = reinterpret_cast<char*>(out);
+    const uint32_t ooff = (frame * (uint32_t)N + 4u * (uint32_t)tau) * 4u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const u32x4 w4 = {word[4 * e], word[4 * e + 1], word[4 * e + 2], word[4 * e + 3]};
+      *reinterpret_cast<u32x4*>(obase + (size_t)ooff + (size_t)(16 * T * e)) = w4;
+    }
+  }
+#ifdef RSP_STAMP
+  STAMP(11);
+  if ((blockIdx.x & 255) == 77 && (threadIdx.x & 63) == 0)
+    printf("stamp wg %u wave %u: load %llu p0 %llu x1 %llu p1 %llu x2 %llu p2mag %llu magw %llu scan %llu cells %llu store %llu total %llu\n",
+           blockIdx.x, threadIdx.x >> 6, st_[1] - st_[0], st_[2] - st_[1], st_[3] - st_[2], st_[4] - st_[3], st_[5] - st_[4],
+           st_[7] - st_[5], st_[8] - st_[7], st_[9] - st_[8], st_[10] - st_[9], st_[11] - st_[10], st_[11] - st_[0]);
+#endif
+#ifdef RSP_COUNT_PATH
+  if (false) {
+#else
+  if (fcount) {
+#endif
+    uint32_t any = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) any |= word[j];
+    if (any & 1u) {  // rare: ~1 peak per 1000 cells; kept compact (a loop, not 16 unrolled copies)
+      uint32_t hits = 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) hits |= (word[j] & 1u) << j;
+      while (hits) {
+        const int j = __ffs(hits) - 1;
+        hits &= hits - 1;
+        uint32_t w = word[0];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) w = (j == q) ? word[q] : w;
+        const uint32_t slot = atomicAdd(det_cnt, 1u);
+        if (slot < (uint32_t)kFrameDetCap)
+          det_stage[slot] = make_uint2((uint32_t)(4 * tau + 4 * T * (j >> 2) + (j & 3)), w);
+      }
+    }
+    // per-frame detection slots (no global atomics): count + first kFrameDetCap peaks
+    __syncthreads();
+    if (live) {
+      const uint32_t cnt = *det_cnt;
+      if (tau == 0) fcount[frame] = cnt;
+      for (uint32_t i = tau; i < min(cnt, (uint32_t)kFrameDetCap); i += T)
+        fdet[(size_t)frame * kFrameDetCap + i] = det_stage[i];
+    }
+  }
 }
 
 // ---------------------------------------------------------------- GOS / ordered-statistic CFAR
@@ -653,8 +1085,9 @@ chain1d_gos_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint
   unsigned char* fbase = smem + (size_t)fl * lay.frame_bytes;
 
   V mg[16];
+  STAMP_DECL;
   front_end<M, FIXED, V>(in, frame, live, tau, fbase, rg, tw, log_lut,
-                         reinterpret_cast<uint32_t*>(smem + (size_t)lay.frame_bytes * FPW), mg);
+                         reinterpret_cast<uint32_t*>(smem + (size_t)lay.frame_bytes * FPW), mg STAMP_ARG);
 
   V* mag = reinterpret_cast<V*>(fbase);  // cell x in [-256, N + 256] at slot pad(x + 256)
   V* o1 = reinterpret_cast<V*>(fbase + lay.o1_off);
@@ -751,8 +1184,31 @@ static hipError_t launch_gos(const Chain1dLaunch& a) {
 }
 
 template <int M>
+static hipError_t launch_quad(const Chain1dLaunch& a) {
+  const uint32_t fpw = frames_per_wg(M);
+  const uint32_t grid = (a.n_frames + fpw - 1) / fpw;
+  const size_t lds = QuadLds<M>::BYTES * fpw + (a.fixed ? QuadLds<M>::ROM_BYTES : 0);
+  static LdsGrant granted[2];
+  if (a.fixed) {
+    auto k = chain1d_quad_kernel<M, true>;
+    hipError_t e = grant_lds(k, lds, a.device, granted[0]);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(wg_size(M)), lds, a.stream, a.in, a.out, a.n_frames,
+                       a.regs, a.twiddles, a.log_lut, a.frame_count, a.frame_det);
+  } else {
+    auto k = chain1d_quad_kernel<M, false>;
+    hipError_t e = grant_lds(k, lds, a.device, granted[1]);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(wg_size(M)), lds, a.stream, a.in, a.out, a.n_frames,
+                       a.regs, a.twiddles, a.log_lut, a.frame_count, a.frame_det);
+  }
+  return hipGetLastError();
+}
+
+template <int M>
 static hipError_t launch_m(const Chain1dLaunch& a) {
   if (a.regs.algorithm == 1) return launch_gos<M>(a);
+  if (quad_tail_supports(M, a.regs) && !a.force_generic_tail) return launch_quad<M>(a);
   const uint32_t fpw = frames_per_wg(M);
   const uint32_t grid = (a.n_frames + fpw - 1) / fpw;
   const size_t lds = FrameLds<M>::BYTES * fpw + (a.fixed ? FrameLds<M>::ROM_BYTES : 0);

@@ -61,6 +61,18 @@ __host__ __device__ constexpr int pad_slots(int n) { return n + (n >> 4); }
 
 __device__ __forceinline__ int pad(int i) { return i + (i >> 4); }
 
+// The image carries one more pad slot per 512 samples (M >= 10): the last pass assigns chunks to
+// threads in bit-reversed order (below), so a 32-lane group then reads samples 2^(M-5) apart, whose
+// slots 2^(M-5) (1 + 1/16) j would share banks; one slot per 512 samples spreads exactly those
+// (and leaves the other exchanges' access shapes conflict-free at 2048 / 4096 points: tools/lds_sim.py).
+// ONE layout for every exchange of a frame: a thread rewrites exactly the slots of the samples it
+// read (in place), which is what lets consecutive exchanges share the image with one barrier each.
+__host__ __device__ constexpr int fft_image_slots(int M) { return pad_slots(1 << M) + (M >= 10 ? (1 << M) >> 9 : 0); }
+template <int M>
+__host__ __device__ constexpr int padx(int i) {
+  return i + (i >> 4) + (M >= 10 ? (i >> 9) : 0);
+}
+
 // sample index of register e (0..15) of thread tau in the pass that owns field [LO, LO+W)
 template <int M, int LO, int W>
 __device__ __forceinline__ int elem_index(int tau, int e) {
@@ -71,19 +83,23 @@ __device__ __forceinline__ int elem_index(int tau, int e) {
   return (high << (LO + W)) | (r << LO) | low;
 }
 
-// LDS slot of that sample = slot_base(tau, g) + slot_delta(r): pad() is additive across the
+// LDS slot of that sample = slot_base(tau, g) + slot_delta(r): the padding is additive across the
 // field bits (no carry can cross them), so the per-register part is a compile-time constant
-// that folds into the ds_read/ds_write offset field.
-template <int M, int LO, int W>
+// that folds into the ds_read/ds_write offset field.  LAST = the exchange in front of the last pass.
+// In the last pass (LO = 0) thread tau takes chunk bitrev(g T + tau) instead of chunk g T + tau: its
+// outputs are then bins (bitrev(p) << (M - W)) | (g T + tau) -- consecutive lanes hold consecutive bins,
+// and what follows the FFT (magnitudes to LDS, spectra to HBM) is written lane-contiguously.
+template <int M, int LO, int W, bool LAST = false>
 __device__ __forceinline__ int slot_base(int tau, int g) {
   constexpr int T = threads_per_frame(M);
-  const int c = g * T + tau;
+  int c = g * T + tau;
+  if constexpr (LAST && LO == 0) c = (int)(__brev((unsigned)c) >> (32 - (M - W)));
   const int i0 = ((c >> LO) << (LO + W)) | (c & ((1 << LO) - 1));
-  return pad(i0);
+  return padx<M>(i0);
 }
-template <int LO, int W>
+template <int M, int LO, int W>
 __host__ __device__ constexpr int slot_delta(int r) {
-  return (r << LO) + ((r << LO) >> 4);
+  return padx<M>(r << LO);
 }
 
 __host__ __device__ constexpr int bitrev_c(int x, int bits) {
@@ -94,11 +110,19 @@ __host__ __device__ constexpr int bitrev_c(int x, int bits) {
 
 // ---------------------------------------------------------------- F32 pieces
 
-// (ax wx - ay wy, ax wy + ay wx) as v_pk_mul_f32 + v_pk_fma_f32: the broadcasts, the
-// swap and the negation are op_sel / neg_lo operand modifiers, not instructions.
+// (ax wx - ay wy, ax wy + ay wx) as v_pk_mul_f32 + v_pk_fma_f32.  The second op reads
+// {ay, ay} x {-wy, wx}: both broadcasts, the swap and the one-sided negation are operand modifiers
+// (op_sel / op_sel_hi / neg_lo).  Written as inline asm because the compiler does not fold a
+// half-negated swap into the modifiers: it materialises {-wy, wx} with v_xor + v_mov for every
+// twiddle, 60 extra VALU instructions per thread and frame at 4096 points (tools/count_insts.sh).
 __device__ __forceinline__ f32x2 cmul(f32x2 a, f32x2 w) {
-  const f32x2 axx = {a.x, a.x}, ayy = {a.y, a.y}, wyx = {-w.y, w.x};
-  return __builtin_elementwise_fma(ayy, wyx, axx * w);
+  const f32x2 axx = {a.x, a.x};
+  const f32x2 t = axx * w;
+  f32x2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+      : "=v"(r)
+      : "v"(a), "v"(w), "v"(t));
+  return r;
 }
 
 // d * exp(-2 pi i k16 / 16), k16 (0..15) a compile-time constant after unrolling.  -i is ONE packed
@@ -162,25 +186,49 @@ __device__ __forceinline__ void dft_dif(f32x2 (&x)[16], int g) {
   }
 }
 
-// One register pass of the F32 FFT. tw = W_N^k, k < N/2 (global, L2-resident).
+// Base twiddles of pass P: W_{2^(LO+W)}^(low 2^j), j < W, for each of the thread's 16 >> W groups,
+// read from the ROM tw = W_N^k, k < N/2 (global, L2-resident).  ALL passes' base twiddles are loaded
+// at the top of the kernel, together with the frame: a load issued between two passes would queue
+// behind the streaming traffic of the other workgroups and stall the pass for its whole (loaded) L2
+// latency (phase stamps, tools/stamp.sh: passes with such a load took 10x the pass without).
 template <int M, int P>
-__device__ __forceinline__ void pass_f32(f32x2 (&x)[16], int tau, const f32x2* __restrict__ tw) {
+struct TwBase {
+  static constexpr int W = plan_w(M, P), G = 16 >> W;
+  f32x2 w[G][W];
+};
+
+template <int M, int P>
+__device__ __forceinline__ void load_tw(int tau, const f32x2* __restrict__ tw, TwBase<M, P>& b) {
   constexpr int W = plan_w(M, P), LO = plan_lo(M, P), G = 16 >> W, T = threads_per_frame(M);
+  if constexpr (LO > 0) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int low = (g * T + tau) & ((1 << LO) - 1);
+      const int base = low << (M - LO - W);  // W_{2^(LO+W)}^low as an exponent of W_N
+#pragma unroll
+      for (int j = 0; j < W; ++j) b.w[g][j] = tw[base << j];
+    }
+  }
+}
+
+// One register pass of the F32 FFT: 2^W-point DFTs, then x[p] *= W_{2^(LO+W)}^(low q), q = bitrev(p),
+// the 2^W - 1 twiddles built from the W base ones with products <= 3 deep.
+template <int M, int P>
+__device__ __forceinline__ void pass_f32(f32x2 (&x)[16], const TwBase<M, P>& b) {
+  constexpr int W = plan_w(M, P), LO = plan_lo(M, P), G = 16 >> W;
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     dft_dif<W>(x, g);
     if constexpr (LO > 0) {
-      const int low = (g * T + tau) & ((1 << LO) - 1);
-      const int base = low << (M - LO - W);  // W_{2^(LO+W)}^low as an exponent of W_N
       f32x2 w[1 << W];
-      w[1] = tw[base];
-      if constexpr (W >= 2) { w[2] = tw[2 * base]; w[3] = cmul(w[1], w[2]); }
+      w[1] = b.w[g][0];
+      if constexpr (W >= 2) { w[2] = b.w[g][1]; w[3] = cmul(w[1], w[2]); }
       if constexpr (W >= 3) {
-        w[4] = tw[4 * base];
+        w[4] = b.w[g][2];
         w[5] = cmul(w[1], w[4]); w[6] = cmul(w[2], w[4]); w[7] = cmul(w[3], w[4]);
       }
       if constexpr (W >= 4) {
-        w[8] = tw[8 * base];
+        w[8] = b.w[g][3];
 #pragma unroll
         for (int q = 1; q < 8; ++q) w[8 + q] = cmul(w[q], w[8]);
       }
@@ -193,38 +241,63 @@ __device__ __forceinline__ void pass_f32(f32x2 (&x)[16], int tau, const f32x2* _
   }
 }
 
+// the base twiddles of every pass of an M-stage frame (passes without twiddles hold nothing)
+template <int M>
+struct TwAll {
+  TwBase<M, 0> p0;
+  TwBase<M, 1> p1;
+  TwBase<M, 2> p2;
+  TwBase<M, 3> p3;
+  __device__ __forceinline__ void load(int tau, const f32x2* __restrict__ tw) {
+    load_tw<M, 0>(tau, tw, p0);
+    load_tw<M, 1>(tau, tw, p1);
+    if constexpr (plan_np(M) > 2) load_tw<M, 2>(tau, tw, p2);
+    if constexpr (plan_np(M) > 3) load_tw<M, 3>(tau, tw, p3);
+  }
+  template <int P>
+  __device__ __forceinline__ const TwBase<M, P>& get() const {
+    if constexpr (P == 0) return p0;
+    else if constexpr (P == 1) return p1;
+    else if constexpr (P == 2) return p2;
+    else return p3;
+  }
+};
+
 // Whole F32 FFT of one frame through the LDS image `buf`.  load(d) returns the sample at the
 // thread's first sample index + d (d is a compile-time constant after unrolling, so the caller's
 // address arithmetic folds into immediates).  On return x[g 2^WL + p] holds, unscaled, bin
-// (bitrev(p) << (M - WL)) | bitrev_{M-WL}(g T + tau), WL = width of the last pass.
+// (bitrev(p) << (M - WL)) | (g T + tau), WL = width of the last pass.
 template <int M, typename Load>
 __device__ __forceinline__ void fft_f32_frame(Load load, int tau, f32x2* buf,
                                               const f32x2* __restrict__ tw, f32x2 (&x)[16]) {
   constexpr int NP = plan_np(M);
+  TwAll<M> twb;
+  twb.load(tau, tw);
   {
     constexpr int W = plan_w(M, 0), LO = plan_lo(M, 0);
 #pragma unroll
     for (int e = 0; e < 16; ++e) x[e] = load(elem_index<M, LO, W>(0, e) - elem_index<M, LO, W>(0, 0));
   }
-  pass_f32<M, 0>(x, tau, tw);
+  pass_f32<M, 0>(x, twb.template get<0>());
   auto exchange = [&](auto pc) {
     constexpr int P = decltype(pc)::value;
     constexpr int W0 = plan_w(M, P - 1), LO0 = plan_lo(M, P - 1);
     constexpr int W1 = plan_w(M, P), LO1 = plan_lo(M, P);
+    constexpr bool LAST = P == NP - 1;
 #pragma unroll
     for (int g = 0; g < (16 >> W0); ++g) {
-      f32x2* b0 = buf + slot_base<M, LO0, W0>(tau, g);
+      f32x2* b0 = buf + slot_base<M, LO0, W0, LAST>(tau, g);
 #pragma unroll
-      for (int r = 0; r < (1 << W0); ++r) b0[slot_delta<LO0, W0>(r)] = x[g * (1 << W0) + r];
+      for (int r = 0; r < (1 << W0); ++r) b0[slot_delta<M, LO0, W0>(r)] = x[g * (1 << W0) + r];
     }
     __syncthreads();
 #pragma unroll
     for (int g = 0; g < (16 >> W1); ++g) {
-      const f32x2* b1 = buf + slot_base<M, LO1, W1>(tau, g);
+      const f32x2* b1 = buf + slot_base<M, LO1, W1, LAST>(tau, g);
 #pragma unroll
-      for (int r = 0; r < (1 << W1); ++r) x[g * (1 << W1) + r] = b1[slot_delta<LO1, W1>(r)];
+      for (int r = 0; r < (1 << W1); ++r) x[g * (1 << W1) + r] = b1[slot_delta<M, LO1, W1>(r)];
     }
-    pass_f32<M, P>(x, tau, tw);
+    pass_f32<M, P>(x, twb.template get<P>());
   };
   exchange(std::integral_constant<int, 1>{});
   if constexpr (NP > 2) exchange(std::integral_constant<int, 2>{});
@@ -241,7 +314,7 @@ __device__ __forceinline__ int first_sample(int tau) {
 template <int M>
 __device__ __forceinline__ int bin_of(int tau, int g, int p) {
   constexpr int NP = plan_np(M), WL = plan_w(M, NP - 1), T = threads_per_frame(M);
-  return (bitrev_c(p, WL) << (M - WL)) | (int)(__brev((unsigned)(g * T + tau)) >> (32 - (M - WL)));
+  return (bitrev_c(p, WL) << (M - WL)) | (g * T + tau);
 }
 
 // ---------------------------------------------------------------- FIXED16 pieces

@@ -41,7 +41,7 @@ range_fft_kernel(const f32x2* __restrict__ in, f32x2* __restrict__ out, uint32_t
   const int tid = threadIdx.x, fl = tid / T, tau = tid % T;
   const uint32_t row = blockIdx.x * FPW + fl;
   const bool live = row < n_rows;
-  f32x2* buf = reinterpret_cast<f32x2*>(smem) + (size_t)fl * pad_slots(N);
+  f32x2* buf = reinterpret_cast<f32x2*>(smem) + (size_t)fl * fft_image_slots(M);
   const f32x2* src = in + (size_t)(live ? row : 0) * N + first_sample<M>(tau);
   f32x2 x[16];
   fft_f32_frame<M>([&](int d) { return src[d]; }, tau, buf, tw, x);
@@ -64,7 +64,7 @@ range_fft_kernel(const f32x2* __restrict__ in, f32x2* __restrict__ out, uint32_t
 // ---------------------------------------------------------------- Doppler pass (columns) + magnitude
 constexpr int kColsPerWg(int MD) { return MD >= 10 ? 8 : 16; }
 // LDS bytes per column: the padded FFT image + 32 B so that adjacent columns start 8 banks apart
-constexpr int kColBytes(int MD) { return 8 * pad_slots(1 << MD) + 32; }
+constexpr int kColBytes(int MD) { return 8 * fft_image_slots(MD) + 32; }
 
 template <int MD>
 __global__ void __launch_bounds__(threads_per_frame(MD) * kColsPerWg(MD))
@@ -312,7 +312,7 @@ template <int M>
 static hipError_t launch_range_m(const f32x2* in, f32x2* out, uint32_t n_rows, const f32x2* tw,
                                  hipStream_t s, int device) {
   const uint32_t fpw = frames_per_wg(M);
-  const size_t lds = (size_t)8 * pad_slots(1 << M) * fpw;
+  const size_t lds = (size_t)8 * fft_image_slots(M) * fpw;
   auto k = range_fft_kernel<M>;
   static LdsGrant granted;
   hipError_t e = grant_lds(k, lds, device, granted);

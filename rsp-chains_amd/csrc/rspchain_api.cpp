@@ -90,6 +90,7 @@ struct rsp_chain {
   // rsp_chain_set_option
   uint32_t opt_max_frames = 0;
   bool opt_force_tiled = false;
+  bool opt_generic_tail = false;
 };
 
 namespace {
@@ -377,6 +378,7 @@ int launch_dense(rsp_chain* c, const void* d_in, size_t n_frames, uint32_t* d_ou
   a.stream = c->stream;
   a.device = c->device;
   a.max_frames_per_launch = c->opt_max_frames;
+  a.force_generic_tail = c->opt_generic_tail;
   if (d_found) {
     a.frame_count = c->d_fcount;
     a.frame_det = c->d_fdet;
@@ -727,6 +729,9 @@ int rsp_chain_set_option(rsp_chain* c, int option, int64_t value) {
       return RSP_OK;
     case RSP_OPT_FORCE_TILED_CFAR2D:
       c->opt_force_tiled = value != 0;
+      return RSP_OK;
+    case RSP_OPT_FORCE_GENERIC_TAIL:
+      c->opt_generic_tail = value != 0;
       return RSP_OK;
     default:
       return fail(RSP_ERR_INVALID, "unknown option %d", option);

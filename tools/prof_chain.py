@@ -20,6 +20,8 @@ rt = (R.RunTimeRspChainParams(fftSize=n, CFARMode="Greatest Of", refWindowSize=3
       if gos else R.RunTimeRspChainParams(fftSize=n, CFARMode="Cell Averaging", refWindowSize=32, guardWindowSize=4, divSum=5))
 dut = R.FftMagCfarChainVanilla(params)
 dut.configure(rt)
+if os.environ.get("RSP_PROF_GENERIC_TAIL"):   # A/B: the per-cell tail instead of the quad tail
+    dut.set_option(dut.FORCE_GENERIC_TAIL, 1)
 sets = 4
 if dtype == R.F32:
     x = R.stimulus.chirp_frames(64, n, seed=1234)
