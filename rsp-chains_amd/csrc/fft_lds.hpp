@@ -186,16 +186,32 @@ __device__ __forceinline__ void dft_dif(f32x2 (&x)[16], int g) {
   }
 }
 
-// Base twiddles of pass P: W_{2^(LO+W)}^(low 2^j), j < W, for each of the thread's 16 >> W groups,
-// read from the ROM tw = W_N^k, k < N/2 (global, L2-resident).  ALL passes' base twiddles are loaded
-// at the top of the kernel, together with the frame: a load issued between two passes would queue
-// behind the streaming traffic of the other workgroups and stall the pass for its whole (loaded) L2
-// latency (phase stamps, tools/stamp.sh: passes with such a load took 10x the pass without).
+// Base twiddles of pass P: W_{2^(LO+W)}^(low 2^j), j < W, for each of the thread's 16 >> W groups.
+// ROM layout (built by the host, rspchain_api.cpp get_rom): per pass with LO > 0 a table indexed by
+// `low` (2^LO entries) of 4 consecutive f32x2 {W^low, W^2low, W^4low, W^8low} = 32 bytes, tables of
+// the passes back to back.  A lane reads its 32 bytes with two 16-byte loads and consecutive lanes read
+// consecutive entries: 16 lines per wave for pass 0 at 4096 points, where indexing one W_N^k table by
+// k = low 2^j touched 60 (as many L2 requests as the frame itself; TCP_TCC_READ_REQ, tools/pmc_tail.sh).
+// ALL passes' base twiddles are loaded at the top of the kernel, together with the frame: a load issued
+// between two passes would queue behind the streaming traffic of the other workgroups and stall the
+// pass for its whole (loaded) L2 latency (phase stamps, tools/stamp.sh).
+__host__ __device__ constexpr int tw_table_entries(int M, int P) {  // f32x2 entries of pass P's table
+  return plan_lo(M, P) > 0 ? (4 << plan_lo(M, P)) : 0;
+}
+__host__ __device__ constexpr int tw_table_offset(int M, int P) {
+  int o = 0;
+  for (int p = 0; p < P; ++p) o += tw_table_entries(M, p);
+  return o;
+}
+__host__ __device__ constexpr int tw_table_total(int M) { return tw_table_offset(M, plan_np(M)); }
+
 template <int M, int P>
 struct TwBase {
   static constexpr int W = plan_w(M, P), G = 16 >> W;
-  f32x2 w[G][W];
+  f32x2 w[G][4];
 };
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int M, int P>
 __device__ __forceinline__ void load_tw(int tau, const f32x2* __restrict__ tw, TwBase<M, P>& b) {
@@ -204,9 +220,15 @@ __device__ __forceinline__ void load_tw(int tau, const f32x2* __restrict__ tw, T
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const int low = (g * T + tau) & ((1 << LO) - 1);
-      const int base = low << (M - LO - W);  // W_{2^(LO+W)}^low as an exponent of W_N
-#pragma unroll
-      for (int j = 0; j < W; ++j) b.w[g][j] = tw[base << j];
+      const f32x4* e = reinterpret_cast<const f32x4*>(tw + tw_table_offset(M, P) + 4 * low);
+      const f32x4 lo = e[0];
+      b.w[g][0] = {lo.x, lo.y};
+      b.w[g][1] = {lo.z, lo.w};
+      if constexpr (W >= 3) {
+        const f32x4 hi = e[1];
+        b.w[g][2] = {hi.x, hi.y};
+        b.w[g][3] = {hi.z, hi.w};
+      }
     }
   }
 }

@@ -17,7 +17,7 @@ struct Chain1dLaunch {
   int log2n;
   bool fixed;
   ChainRegs regs;
-  const void* twiddles;    // device: W_N^k, k < N/2 (f32x2, or packed Q2.14 pairs)
+  const void* twiddles;    // device: F32 per-pass base-twiddle tables (fft_lds.hpp load_tw); FIXED16 W_N^k, k < N/2, packed Q2.14 pairs
   const int16_t* log_lut;  // device: log2 fraction table (FIXED16, mag mode 1)
   // optional fused detection output: per-frame peak count + first kFrameDetCap {bin, word}
   uint32_t* frame_count;   // device: n_frames, or NULL

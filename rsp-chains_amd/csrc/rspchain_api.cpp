@@ -14,6 +14,7 @@
 
 #include "../../include/rspchain.h"
 #include "chain_regs.hpp"
+#include "fft_lds.hpp"
 #include "kernels.hpp"
 
 namespace {
@@ -295,7 +296,7 @@ rsp::ChainRegs snapshot(const rsp_chain* c) {
   return r;
 }
 
-// Twiddle ROM W_N^k = exp(-2 pi i k / N), k < N/2, built once per frame size.
+// Twiddle ROM, built once per frame size: F32 = the per-pass base-twiddle tables of fft_lds.hpp, FIXED16 = W_N^k, k < N/2.
 int get_rom(rsp_chain* c, int log2n, const void** out) {
   auto it = c->rom.find(log2n);
   if (it != c->rom.end()) {
@@ -304,12 +305,32 @@ int get_rom(rsp_chain* c, int log2n, const void** out) {
   }
   const int n = 1 << log2n, half = n / 2;
   TwiddleRom rom;
-  if (c->p.dtype == RSP_DTYPE_F32) {
+  if (c->p.dtype == RSP_DTYPE_F32 && log2n < rsp::kMinLog2N) {
+    // 16..128-point frames (small.hip): plain W_N^k, k < N/2
     std::vector<float> h(2 * (size_t)half);
     for (int k = 0; k < half; ++k) {
       const double a = -2.0 * M_PI * (double)k / (double)n;
       h[2 * k] = (float)std::cos(a);
       h[2 * k + 1] = (float)std::sin(a);
+    }
+    HIP_TRY(hipMalloc(&rom.d, h.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(rom.d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  } else if (c->p.dtype == RSP_DTYPE_F32) {
+    // per pass with LO > 0: entry `low` = {W^low, W^2low, W^4low, W^8low} of W = W_{2^(LO+W)}
+    // (fft_lds.hpp load_tw), computed in double
+    std::vector<float> h(2 * (size_t)rsp::tw_table_total(log2n));
+    for (int p = 0; p < rsp::plan_np(log2n); ++p) {
+      const int lo = rsp::plan_lo(log2n, p), w = rsp::plan_w(log2n, p);
+      if (lo <= 0) continue;
+      float* t = h.data() + 2 * (size_t)rsp::tw_table_offset(log2n, p);
+      for (int low = 0; low < (1 << lo); ++low) {
+        for (int j = 0; j < 4; ++j) {
+          const long long e = (long long)low << j;  // exponent of W_{2^(lo+w)}; j >= w entries are never read
+          const double a = -2.0 * M_PI * (double)e / (double)(1 << (lo + w));
+          t[2 * (4 * low + j)] = (float)std::cos(a);
+          t[2 * (4 * low + j) + 1] = (float)std::sin(a);
+        }
+      }
     }
     HIP_TRY(hipMalloc(&rom.d, h.size() * sizeof(float)));
     HIP_TRY(hipMemcpy(rom.d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
