@@ -1264,16 +1264,16 @@ hipError_t launch_chain1d(const Chain1dLaunch& a0) {
 // ---------------------------------------------------------------- detection compaction
 
 // Last-workgroup epilogue shared by both compaction kernels: counters = {found, cursor, ticket}, all
-// zero on entry.  Every workgroup has added its share (device-scope atomics) before it takes a
-// ticket; the workgroup that draws the last ticket publishes {found, stored} and re-zeroes the
-// counters for the next launch on this stream.
+// zero on entry.  Thread 0 of every workgroup has added its share with RETURNING device-scope atomics
+// (so they have been performed when it goes on) before it takes a ticket; the workgroup that draws the
+// last ticket publishes {found, stored} and re-zeroes the counters for the next launch on this stream.
+// No __threadfence: only the counters travel between workgroups, and they are only ever touched by
+// device-scope atomics -- an agent-scope fence per workgroup writes back / invalidates L2 on this
+// multi-XCD part and cost 180 ns per workgroup (750 us for the 4096 workgroups of a 67 M-cell map).
 __device__ __forceinline__ void publish_counts(uint32_t* counters, uint32_t cap, uint32_t* d_count) {
-  __threadfence();
-  __syncthreads();
   if (threadIdx.x == 0) {
     const uint32_t ticket = atomicAdd(&counters[2], 1u);
     if (ticket == gridDim.x - 1) {
-      __threadfence();
       const uint32_t found = atomicExch(&counters[0], 0u);
       const uint32_t cursor = atomicExch(&counters[1], 0u);
       atomicExch(&counters[2], 0u);
@@ -1281,6 +1281,17 @@ __device__ __forceinline__ void publish_counts(uint32_t* counters, uint32_t cap,
       d_count[1] = cursor < cap ? cursor : cap;
     }
   }
+}
+
+// found / cursor shares of a workgroup (thread 0 only): returning atomics, see publish_counts
+__device__ __forceinline__ uint32_t reserve_block(uint32_t* counters, uint32_t found, uint32_t entries) {
+  uint32_t base = 0u;
+  if (found) {
+    const uint32_t r = atomicAdd(&counters[0], found);
+    asm volatile("" ::"v"(r));  // keep the return value live: the wave waits for the atomic
+  }
+  if (entries) base = atomicAdd(&counters[1], entries);
+  return base;
 }
 
 // Per-frame slots written by chain1d_kernel -> one compact list.  One thread per
@@ -1317,8 +1328,7 @@ compact_frames_kernel(const uint32_t* __restrict__ fcount, const uint2* __restri
   if (threadIdx.x == 0) {
     const uint32_t tot = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
     const uint32_t fnd = wave_found[0] + wave_found[1] + wave_found[2] + wave_found[3];
-    if (fnd) atomicAdd(&counters[0], fnd);
-    base_sh = tot ? atomicAdd(&counters[1], tot) : 0u;
+    base_sh = reserve_block(counters, fnd, tot);
   }
   __syncthreads();
   const uint32_t base = base_sh + off;
@@ -1374,59 +1384,99 @@ hipError_t launch_compact_frames(const uint32_t* fcount, const uint2* fdet, uint
   return hipGetLastError();
 }
 
-// Dense words -> compact list of the peak cells (word bit 0, Tester:165).  Each
-// workgroup owns a contiguous run of cells: pass 1 counts its peaks, one global
-// atomic reserves its block of the list, pass 2 (words now L2-resident) writes.
+// Dense words -> compact list of the peak cells (word bit 0, Tester:165).  One pass: a workgroup
+// owns 16 384 consecutive cells, every thread loads its 64 words with four 16-byte loads issued
+// together (16 KiB in flight per workgroup: the kernel runs at streaming rate, 4 B per cell), counts
+// its peaks, the workgroup reserves a block of the list with ONE global atomic and the (rare) peaks
+// are written from registers.
+constexpr int kCompactCellsPerWg = 16384;
+
 __global__ void __launch_bounds__(256)
-compact_kernel(const uint32_t* __restrict__ words, uint64_t n_cells, uint64_t cells_per_wg,
-               uint32_t log2_row, uint32_t log2_rows_per_frame, rsp_detection* __restrict__ list,
-               uint32_t cap, uint32_t* __restrict__ counters, uint32_t* __restrict__ d_count) {
+compact_kernel(const uint32_t* __restrict__ words, uint64_t n_cells, uint32_t log2_row,
+               uint32_t log2_rows_per_frame, rsp_detection* __restrict__ list, uint32_t cap,
+               uint32_t* __restrict__ counters, uint32_t* __restrict__ d_count) {
   __shared__ uint32_t wave_cnt[4];
   __shared__ uint32_t base_sh;
-  const uint64_t lo = (uint64_t)blockIdx.x * cells_per_wg;
-  const uint64_t hi = min(lo + cells_per_wg, n_cells);
+  const uint64_t lo = (uint64_t)blockIdx.x * kCompactCellsPerWg;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // thread t, load j covers cells lo + 1024 j + 4 t .. + 3 (n_cells is a multiple of 4: whole rows of >= 16 cells)
+  u32x4 w[16];
   uint32_t mine = 0;
-  for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) mine += words[i] & 1u;
-  uint32_t tot = mine;
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
-  if (lane == 0) wave_cnt[wave] = tot;
+  for (int j = 0; j < 16; ++j) {
+    const uint64_t c = lo + 1024u * j + 4u * threadIdx.x;
+    w[j] = c < n_cells ? *reinterpret_cast<const u32x4*>(words + c) : u32x4{0u, 0u, 0u, 0u};
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) mine += (w[j].x & 1u) + (w[j].y & 1u) + (w[j].z & 1u) + (w[j].w & 1u);
+  uint32_t inc = mine;  // inclusive scan over the wave
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(inc, d);
+    if (lane >= d) inc += t;
+  }
+  if (lane == 63) wave_cnt[wave] = inc;
   __syncthreads();
   if (threadIdx.x == 0) {
     const uint32_t t = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-    if (t) atomicAdd(&counters[0], t);
-    base_sh = t ? atomicAdd(&counters[1], t) : 0u;
-    wave_cnt[0] = 0;  // becomes the in-workgroup cursor
+    base_sh = reserve_block(counters, t, t);
   }
   __syncthreads();
-  for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) {
-    const uint32_t w = words[i];
-    if (w & 1u) {
-      const uint32_t slot = base_sh + atomicAdd(&wave_cnt[0], 1u);
-      if (slot < cap) {
-        rsp_detection d;
-        d.bin = (uint32_t)(i & ((1ull << log2_row) - 1ull));
-        const uint64_t row = i >> log2_row;
-        d.doppler = (uint32_t)(row & ((1ull << log2_rows_per_frame) - 1ull));
-        d.frame = (uint32_t)(row >> log2_rows_per_frame);
-        d.word = w;
-        list[slot] = d;
+  if (mine) {  // rare: the thread's words are read again (L2 hits) by a compact loop instead of keeping 64 registers live
+    uint32_t slot = base_sh + inc - mine;
+    for (int w0 = 0; w0 < wave; ++w0) slot += wave_cnt[w0];
+#pragma unroll 1
+    for (int j = 0; j < 16; ++j) {
+      const uint64_t c = lo + 1024u * j + 4u * threadIdx.x;
+      if (c >= n_cells) break;
+      const u32x4 v4 = *reinterpret_cast<const u32x4*>(words + c);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t v = v4[q];
+        if (v & 1u) {
+          if (slot < cap) {
+            const uint64_t i = c + q;
+            rsp_detection d;
+            d.bin = (uint32_t)(i & ((1ull << log2_row) - 1ull));
+            const uint64_t row = i >> log2_row;
+            d.doppler = (uint32_t)(row & ((1ull << log2_rows_per_frame) - 1ull));
+            d.frame = (uint32_t)(row >> log2_rows_per_frame);
+            d.word = v;
+            list[slot] = d;
+          }
+          ++slot;
+        }
       }
     }
   }
-  publish_counts(counters, cap, d_count);
+}
+
+// {found, cursor} -> d_count, counters re-zeroed: one thread, its own launch.  The dense compaction runs
+// thousands of workgroups; a ticket per workgroup on ONE address (publish_counts) serialises at the
+// memory side (~13 ns each) and cost more than this ~2 us launch.
+__global__ void compact_finalize_kernel(uint32_t* __restrict__ counters, uint32_t cap, uint32_t* __restrict__ d_count,
+                                        bool use_found) {
+  const uint32_t found = atomicExch(&counters[0], 0u);
+  uint32_t cursor = atomicExch(&counters[1], 0u);
+  if (use_found) cursor = found;  // lists appended peak by peak (2-D CFAR kernels): every peak found was offered a slot
+  d_count[0] = found;
+  d_count[1] = cursor < cap ? cursor : cap;
+}
+
+hipError_t launch_compact_finalize(uint32_t* counters, uint32_t cap, uint32_t* d_count, bool stored_is_found,
+                                   hipStream_t stream) {
+  hipLaunchKernelGGL(compact_finalize_kernel, dim3(1), dim3(1), 0, stream, counters, cap, d_count, stored_is_found);
+  return hipGetLastError();
 }
 
 hipError_t launch_compact(const uint32_t* words, uint64_t n_cells, uint32_t log2_row,
                           uint32_t log2_rows_per_frame, rsp_detection* list, uint32_t cap,
                           uint32_t* counters, uint32_t* d_count, hipStream_t stream) {
   if (n_cells == 0) return hipMemsetAsync(d_count, 0, 2 * sizeof(uint32_t), stream);
-  uint64_t blocks = (n_cells + 4095) / 4096;
-  if (blocks > 4096) blocks = 4096;
-  const uint64_t per = (n_cells + blocks - 1) / blocks;
+  const uint64_t blocks = (n_cells + kCompactCellsPerWg - 1) / kCompactCellsPerWg;
   hipLaunchKernelGGL(compact_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, words, n_cells,
-                     per, log2_row, log2_rows_per_frame, list, cap, counters, d_count);
+                     log2_row, log2_rows_per_frame, list, cap, counters, d_count);
+  hipLaunchKernelGGL(compact_finalize_kernel, dim3(1), dim3(1), 0, stream, counters, cap, d_count, false);
   return hipGetLastError();
 }
 

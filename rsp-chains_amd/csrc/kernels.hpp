@@ -47,6 +47,12 @@ struct Rd2dLaunch {
   hipStream_t stream;
   int device;
   bool force_tiled_cfar;  // tests: take the run-time-window kernel even for the compile-time windows
+  // optional fused detection list: the CFAR kernel appends its peak cells itself (one device-scope
+  // atomic per PEAK, none otherwise), so no second pass over the dense words is needed
+  rsp_detection* det_list;  // device, or NULL
+  uint32_t det_cap;
+  uint32_t* det_counters;   // kCompactCounters words, zero on entry; [0] = [1] = peaks appended so far
+  uint32_t* det_count;      // device uint32[2]: {found, stored}, written by the finalize launch
 };
 hipError_t launch_rd2d(const Rd2dLaunch& a);
 
@@ -62,6 +68,8 @@ hipError_t launch_compact_frames(const uint32_t* fcount, const uint2* fdet, uint
                                  const uint32_t* words, int log2n, rsp_detection* list, uint32_t cap,
                                  uint32_t* counters, uint32_t* d_count, hipStream_t stream);
 
+hipError_t launch_compact_finalize(uint32_t* counters, uint32_t cap, uint32_t* d_count, bool stored_is_found,
+                                   hipStream_t stream);
 hipError_t launch_compact(const uint32_t* words, uint64_t n_cells, uint32_t log2_row,
                           uint32_t log2_rows_per_frame, rsp_detection* list, uint32_t cap,
                           uint32_t* counters, uint32_t* d_count, hipStream_t stream);

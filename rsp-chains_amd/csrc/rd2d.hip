@@ -97,6 +97,23 @@ doppler_mag_kernel(const f32x2* __restrict__ in, float* __restrict__ mag, uint32
   }
 }
 
+// ---------------------------------------------------------------- fused detection list
+// A peak cell appends itself: ONE device-scope atomic per peak (peaks are ~1e-5 of the cells), none
+// otherwise.  counters[0] counts the peaks (zero on entry, re-zeroed by the finalize launch, which also
+// publishes stored = min(found, cap)).
+__device__ __forceinline__ void append_peak(rsp_detection* __restrict__ list, uint32_t cap, uint32_t* __restrict__ counters,
+                                            uint32_t ch, uint32_t doppler, uint32_t range, uint32_t word) {
+  const uint32_t slot = atomicAdd(&counters[0], 1u);  // found; the finalize launch sets stored = min(found, cap)
+  if (slot < cap) {
+    rsp_detection d;
+    d.frame = ch;
+    d.bin = range;
+    d.doppler = doppler;
+    d.word = word;
+    list[slot] = d;
+  }
+}
+
 // ---------------------------------------------------------------- 2-D CA-CFAR
 // Training region = (2(ref_r+guard_r)+1) x (2(ref_d+guard_d)+1) box minus the guard box; out-of-map
 // range cells read zero (edge 0) or wrap (edge 1), Doppler is cyclic; statistic = sum / count.
@@ -107,7 +124,8 @@ constexpr int kTD = 32, kTR = 64;  // output tile: 32 Doppler rows x 64 range bi
 template <int SRR, int SGR, int SRD, int SGD>
 __global__ void __launch_bounds__(256)
 cfar2d_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_t nd, uint32_t nr,
-              int ref_r_rt, int guard_r_rt, int ref_d_rt, int guard_d_rt, int edge, float kA, float kB) {
+              int ref_r_rt, int guard_r_rt, int ref_d_rt, int guard_d_rt, int edge, float kA, float kB,
+              rsp_detection* __restrict__ det_list, uint32_t det_cap, uint32_t* __restrict__ det_counters) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int ref_r = SRR >= 0 ? SRR : ref_r_rt, guard_r = SGR >= 0 ? SGR : guard_r_rt;
   const int ref_d = SRD >= 0 ? SRD : ref_d_rt, guard_d = SGD >= 0 ? SGD : guard_d_rt;
@@ -194,7 +212,9 @@ cfar2d_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_
     for (int j = 0; j < kTD / 4; ++j) {
       const float thr = __fmaf_rn(so - si, kAc, kB);
       const float cut = m[(dseg + j + hd) * MS + c + hr];
-      dst[(size_t)j * nr] = (__float_as_uint(thr) & ~1u) | (uint32_t)(cut > thr);
+      const uint32_t wd = (__float_as_uint(thr) & ~1u) | (uint32_t)(cut > thr);
+      dst[(size_t)j * nr] = wd;
+      if (det_list && (wd & 1u)) append_peak(det_list, det_cap, det_counters, ch, (uint32_t)(d0 + dseg + j), (uint32_t)(r0 + c), wd);
       so += co[(j + hd + 1) * (kTR + 1)] - co[(j - hd) * (kTR + 1)];
       si += ci[(j + guard_d + 1) * (kTR + 1)] - ci[(j - guard_d) * (kTR + 1)];
     }
@@ -233,7 +253,9 @@ __device__ __forceinline__ float prefix_at(float p0, float p1, int lane) {
 }
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kWalkRing = 32;
+constexpr int kWalkStage = 126;  // detections a wave stages in LDS per segment (2 KiB per wave)
 constexpr int walk_lb(int hr) { return (hr + 2) / 2; }
 constexpr int walk_le(int hr) { return (126 - hr) / 2; }
 constexpr int walk_outw(int hr) { return 2 * (walk_le(hr) - walk_lb(hr) + 1); }
@@ -241,7 +263,8 @@ constexpr int walk_outw(int hr) { return 2 * (walk_le(hr) - walk_lb(hr) + 1); }
 template <int RR, int GR, int RD, int GD, int SEG>
 __global__ void __launch_bounds__(256)
 cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_t nd, uint32_t nr,
-                   uint32_t strips, int edge, float kA, float kB) {
+                   uint32_t strips, int edge, float kA, float kB,
+                   rsp_detection* __restrict__ det_list, uint32_t det_cap, uint32_t* __restrict__ det_counters) {
   constexpr int HR = RR + GR, HD = RD + GD, SPAN = 2 * HD + 2, RING = kWalkRing;
   constexpr int LB = walk_lb(HR), LE = walk_le(HR), OUTW = walk_outw(HR);
   static_assert(SPAN < RING && SEG % RING == 0, "ring holds the taps plus at least one row in flight");
@@ -272,6 +295,13 @@ cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, ui
     const uint32_t d = (uint32_t)((d0 - HD + p) & ((int)nd - 1));
     return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_in, voff_in, d * nr * 4u, 0));
   };
+  // fused detection list: peaks are staged in a wave-private LDS buffer during the walk (LDS atomics
+  // only: a vector-memory atomic inside the walk, even in a never-taken branch, makes the wait-count
+  // merge drain the row prefetch on every step -- 4x slower, measured) and flushed after it
+  __shared__ uint32_t stage_cnt[4];
+  __shared__ u32x4 stage[4][kWalkStage];
+  const uint32_t det_mask = (det_list && owner) ? 1u : 0u;
+  if (lane == 0) stage_cnt[w] = 0u;
   f32x2 ring[RING];
 #pragma unroll
   for (int p = 0; p < RING - 1; ++p) ring[p] = load_row(p);
@@ -297,11 +327,49 @@ cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, ui
       wd.x = (__float_as_uint(t0) & ~1u) | (uint32_t)(cut.x > t0);
       wd.y = (__float_as_uint(t1) & ~1u) | (uint32_t)(cut.y > t1);
       __builtin_amdgcn_raw_buffer_store_b64(wd, rsrc_out, voff_out, (uint32_t)(d0 + i) * nr * 4u, 0);
+      if ((wd.x | wd.y) & det_mask) {  // rare
+        if (wd.x & 1u) {
+          const uint32_t sl = atomicAdd(&stage_cnt[w], 1u);
+          if (sl < (uint32_t)kWalkStage) stage[w][sl] = u32x4{ch, (uint32_t)col, (uint32_t)(d0 + i), wd.x};
+        }
+        if (wd.y & 1u) {
+          const uint32_t sl = atomicAdd(&stage_cnt[w], 1u);
+          if (sl < (uint32_t)kWalkStage) stage[w][sl] = u32x4{ch, (uint32_t)col + 1u, (uint32_t)(d0 + i), wd.y};
+        }
+      }
       vo += ring[(u + SPAN - 1) % RING] - ring[u];
       vi += ring[(u + HD + GD + 1) % RING] - ring[(u + HD - GD) % RING];
       // keep every row's load at the top of its own step: the scheduler would otherwise sink the
       // loads next to their first use, 10 rows later, and drain the prefetch pipeline
       __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (det_list) {
+    const uint32_t n = stage_cnt[w];  // wave-private: this wave's LDS operations execute in order
+    if (n > 0u && n <= (uint32_t)kWalkStage) {
+      uint32_t base = 0u;
+      if (lane == 0) base = atomicAdd(&det_counters[0], n);  // ONE device-scope atomic per wave that found something
+      base = __builtin_amdgcn_readfirstlane(base);
+      for (uint32_t k = lane; k < n; k += 64) {
+        if (base + k < det_cap) {
+          const u32x4 e = stage[w][k];
+          rsp_detection d;
+          d.frame = e.x;
+          d.bin = e.y;
+          d.doppler = e.z;
+          d.word = e.w;
+          det_list[base + k] = d;
+        }
+      }
+    } else if (n > (uint32_t)kWalkStage && owner) {
+      // more peaks than the staging holds (a wave's 2 x 64 x SEG cells with > kWalkStage peaks: thresholds far
+      // below the noise): every lane reads its own words back and appends them one by one
+#pragma unroll 1
+      for (int i = 0; i < SEG; ++i) {
+        const u32x2 wd = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_out, voff_out, (uint32_t)(d0 + i) * nr * 4u, 1 /* glc */));
+        if (wd.x & 1u) append_peak(det_list, det_cap, det_counters, ch, (uint32_t)(d0 + i), (uint32_t)col, wd.x);
+        if (wd.y & 1u) append_peak(det_list, det_cap, det_counters, ch, (uint32_t)(d0 + i), (uint32_t)col + 1u, wd.y);
+      }
     }
   }
 }
@@ -372,16 +440,22 @@ hipError_t launch_rd2d(const Rd2dLaunch& a) {
     // 64 rows per wave: 32 measures the same, 128 is 6 % slower (fewer waves to hide the row latency)
     constexpr uint32_t SEG = 64;
     hipLaunchKernelGGL((cfar2d_walk_kernel<8, 2, 8, 2, SEG>), dim3(a.n_ch * strips * (nd / SEG / 4)), dim3(256), 0,
-                       a.stream, a.scratch_mag, a.out, nd, nr, strips, a.regs.edge, kA, kB);
-    return hipGetLastError();
+                       a.stream, a.scratch_mag, a.out, nd, nr, strips, a.regs.edge, kA, kB, a.det_list, a.det_cap,
+                       a.det_counters);
+    e = hipGetLastError();
+    if (e == hipSuccess && a.det_list) e = launch_compact_finalize(a.det_counters, a.det_cap, a.det_count, true, a.stream);
+    return e;
   }
   auto k = cfar2d_kernel<-1, -1, -1, -1>;
   static LdsGrant granted;
   e = grant_lds(k, lds, a.device, granted);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3(a.n_ch * (nr / kTR) * (nd / kTD)), dim3(256), lds, a.stream, a.scratch_mag, a.out,
-                     nd, nr, a.regs.R, a.regs.G, a.ref_d, a.guard_d, a.regs.edge, kA, kB);
-  return hipGetLastError();
+                     nd, nr, a.regs.R, a.regs.G, a.ref_d, a.guard_d, a.regs.edge, kA, kB, a.det_list, a.det_cap,
+                     a.det_counters);
+  e = hipGetLastError();
+  if (e == hipSuccess && a.det_list) e = launch_compact_finalize(a.det_counters, a.det_cap, a.det_count, true, a.stream);
+  return e;
 }
 
 }  // namespace rsp

@@ -362,16 +362,14 @@ int ensure(void** ptr, size_t* have, size_t want) {
 
 size_t beat_bytes(const rsp_chain* c) { return c->p.dtype == RSP_DTYPE_F32 ? 8 : 4; }
 
-int launch_rd(rsp_chain* c, const void* d_in, size_t n_ch, uint32_t* d_out);
+int launch_rd(rsp_chain* c, const void* d_in, size_t n_ch, uint32_t* d_out, rsp_detection* d_list = nullptr,
+              uint32_t cap = 0, uint32_t* d_found = nullptr);
 
 int launch_dense(rsp_chain* c, const void* d_in, size_t n_frames, uint32_t* d_out,
                  rsp_detection* d_list = nullptr, uint32_t cap = 0, uint32_t* d_found = nullptr) {
   int rc = check_regs(c);
   if (rc != RSP_OK) return rc;
-  if (c->p.dopplerPoints) {
-    if (d_found) return fail(RSP_ERR_UNSUPPORTED, "2-D chain: use rsp_chain_detections_device on the dense words");
-    return launch_rd(c, d_in, n_frames, d_out);
-  }
+  if (c->p.dopplerPoints) return launch_rd(c, d_in, n_frames, d_out, d_list, cap, d_found);
   if (n_frames > 0x7fffffffull) return fail(RSP_ERR_INVALID, "n_frames = %zu too large for one call", n_frames);
   if (n_frames && (!d_in || (!d_out && !d_found))) return fail(RSP_ERR_INVALID, "NULL buffer");
   HIP_TRY(hipSetDevice(c->device));
@@ -425,9 +423,13 @@ int launch_dense(rsp_chain* c, const void* d_in, size_t n_frames, uint32_t* d_ou
   return RSP_OK;
 }
 
-int launch_rd(rsp_chain* c, const void* d_in, size_t n_ch, uint32_t* d_out) {
-  if (n_ch == 0) return RSP_OK;
-  if (!d_in || !d_out) return fail(RSP_ERR_INVALID, "NULL buffer");
+int launch_rd(rsp_chain* c, const void* d_in, size_t n_ch, uint32_t* d_out, rsp_detection* d_list, uint32_t cap,
+              uint32_t* d_found) {
+  if (n_ch == 0) {
+    if (d_found) HIP_TRY(hipMemsetAsync(d_found, 0, 2 * sizeof(uint32_t), c->stream));
+    return RSP_OK;
+  }
+  if (!d_in || !d_out) return fail(RSP_ERR_INVALID, "NULL buffer (the 2-D chain always writes its dense words)");
   HIP_TRY(hipSetDevice(c->device));
   const size_t cells = (n_ch * (size_t)c->p.dopplerPoints) << c->fft_stages;
   if (n_ch > 0xffffu || cells > 0x7fffffffull) return fail(RSP_ERR_INVALID, "2-D chain: %zu channels too many for one call", n_ch);
@@ -453,6 +455,12 @@ int launch_rd(rsp_chain* c, const void* d_in, size_t n_ch, uint32_t* d_out) {
   a.stream = c->stream;
   a.device = c->device;
   a.force_tiled_cfar = c->opt_force_tiled;
+  if (d_found) {
+    a.det_list = d_list;
+    a.det_cap = cap;
+    a.det_counters = c->d_ctr;
+    a.det_count = d_found;
+  }
   hipEvent_t pe1 = nullptr;
   if (c->profiling) {  // the 2-D chain's three kernels as one bracket
     if (c->prof_used == c->prof_events.size()) {
@@ -717,16 +725,8 @@ int rsp_chain_process_detections(rsp_chain* c, const void* in_beats, size_t n_fr
   if (rc != RSP_OK) return rc;
   c->d_list_cap = list_bytes / sizeof(rsp_detection);
   HIP_TRY(hipMemcpyAsync(c->d_in, in_beats, cells * beat_bytes(c), hipMemcpyHostToDevice, c->stream));
-  if (c->p.dopplerPoints) {
-    rc = launch_dense(c, c->d_in, n_frames, c->d_out);
-    if (rc != RSP_OK) return rc;
-    const uint32_t log2_rows = (uint32_t)ilog2(c->p.dopplerPoints);
-    HIP_TRY(rsp::launch_compact(c->d_out, cells, c->fft_stages, log2_rows, c->d_list, (uint32_t)cap, c->d_ctr,
-                                c->d_count, c->stream));
-  } else {
-    rc = launch_dense(c, c->d_in, n_frames, c->d_out, c->d_list, (uint32_t)cap, c->d_count);
-    if (rc != RSP_OK) return rc;
-  }
+  rc = launch_dense(c, c->d_in, n_frames, c->d_out, c->d_list, (uint32_t)cap, c->d_count);
+  if (rc != RSP_OK) return rc;
   uint32_t counts[2] = {0, 0};  // {found, stored}
   HIP_TRY(hipMemcpyAsync(counts, c->d_count, sizeof(counts), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));

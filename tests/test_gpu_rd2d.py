@@ -144,27 +144,47 @@ def test_rd2d_walker_agrees_with_tiled_kernel(gpu, edge):
     np.testing.assert_allclose(ta, tb, rtol=1e-5)   # half the tolerance each is held to against the oracle
 
 
-def test_rd2d_detection_list(gpu):
+@pytest.mark.parametrize("tiled", [0, 1])
+def test_rd2d_detection_list(gpu, tiled):
+    """The 2-D chain's detection list three ways: appended by the CFAR kernel itself (fused call), compacted
+    from the dense words (stand-alone call) and through the host-buffer call -- all equal to the peaks of the
+    dense words; a list capacity smaller than the number of peaks truncates without garbage."""
     nr, nd, n_ch = 512, 256, 3
     params = rd_params(nr, nd)
     rt = R.RunTimeRspChainParams(fftSize=nr, CFARMode="Cell Averaging", refWindowSize=8, guardWindowSize=2, divSum=4,
-                                 thresholdScaler=4.0)
+                                 thresholdScaler=2.0)   # a few hundred peaks
     x, _ = targets(n_ch, nd, nr, seed=77)
     cap = 1 << 16
     with R.FftMagCfarChainVanilla(params) as dut:
         dut.configure(rt)
+        dut.set_option(dut.FORCE_TILED_CFAR2D, tiled)
         d_in = R.DeviceBuffer(x.nbytes); d_in.upload(x)
-        d_out = R.DeviceBuffer(x.size * 4)
+        d_out, d_out2 = R.DeviceBuffer(x.size * 4), R.DeviceBuffer(x.size * 4)
         d_list, d_cnt = R.DeviceBuffer(cap * 16), R.DeviceBuffer(8)
+        d_list2, d_cnt2 = R.DeviceBuffer(cap * 16), R.DeviceBuffer(8)
         dut.process_device(d_in.ptr, n_ch, d_out.ptr)
         dut.detections_device(d_out.ptr, n_ch, d_list.ptr, cap, d_cnt.ptr)
+        dut.process_detect_device(d_in.ptr, n_ch, d_out2.ptr, d_list2.ptr, cap, d_cnt2.ptr)
         dut.synchronize()
         dense = d_out.download(np.uint32, x.size).reshape(n_ch, nd, nr)
-        found = int(d_cnt.download(np.uint32, 1)[0])
-        lst = d_list.download(np.uint32, found * 4).reshape(found, 4)
-    ch, d, r = np.nonzero(dense & 1)
-    want = sorted(zip(ch.tolist(), r.tolist(), d.tolist(), dense[ch, d, r].tolist()))
-    assert sorted(map(tuple, lst.tolist())) == want      # {frame = channel, bin = range, doppler, word}
+        assert np.array_equal(dense, d_out2.download(np.uint32, x.size).reshape(n_ch, nd, nr))
+        ch, d, r = np.nonzero(dense & 1)
+        want = sorted(zip(ch.tolist(), r.tolist(), d.tolist(), dense[ch, d, r].tolist()))
+        assert len(want) > 100
+        for lst_buf, cnt_buf in ((d_list, d_cnt), (d_list2, d_cnt2)):
+            found, stored = (int(v) for v in cnt_buf.download(np.uint32, 2))
+            assert found == stored == len(want)
+            lst = lst_buf.download(np.uint32, found * 4).reshape(found, 4)
+            assert sorted(map(tuple, lst.tolist())) == want      # {frame = channel, bin = range, doppler, word}
+        dut.process_detect_device(d_in.ptr, n_ch, d_out2.ptr, d_list2.ptr, 50, d_cnt2.ptr)   # cap < peaks
+        dut.synchronize()
+        found, stored = (int(v) for v in d_cnt2.download(np.uint32, 2))
+        assert found == len(want) and stored == 50
+        assert set(map(tuple, d_list2.download(np.uint32, 200).reshape(50, 4).tolist())) <= set(want)
+        det, found_h = dut.detections(x)
+        assert found_h == len(want)
+        assert [(int(a), int(b), int(c), int(w)) for a, b, c, w in zip(det["frame"], det["bin"], det["doppler"], det["word"])] == \
+            sorted(want, key=lambda t: (t[0], t[2], t[1]))
 
 
 def test_rd2d_rejects_what_it_does_not_implement(gpu):

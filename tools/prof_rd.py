@@ -20,9 +20,18 @@ sets = 3
 ins, outs = [], []
 for s in range(sets):
     b = R.DeviceBuffer(x.nbytes); b.upload(x); ins.append(b); outs.append(R.DeviceBuffer(x.size * 4))
-for i in range(3): dut.process_device(ins[i % sets].ptr, n_ch, outs[i % sets].ptr)
+with_list = len(sys.argv) > 5 and sys.argv[5] == "list"   # + compaction of the dense words into a detection list
+fused = len(sys.argv) > 5 and sys.argv[5] == "fused"       # the CFAR kernel appends the list itself
+cap = 1 << 16
+lst, cnt = R.DeviceBuffer(cap * 16), R.DeviceBuffer(8)
+def step(i):
+    if fused: dut.process_detect_device(ins[i % sets].ptr, n_ch, outs[i % sets].ptr, lst.ptr, cap, cnt.ptr)
+    else: dut.process_device(ins[i % sets].ptr, n_ch, outs[i % sets].ptr)
+    if with_list: dut.detections_device(outs[i % sets].ptr, n_ch, lst.ptr, cap, cnt.ptr)
+for i in range(3): step(i)
 dut.synchronize(); dut.timer_start()
-for i in range(reps): dut.process_device(ins[i % sets].ptr, n_ch, outs[i % sets].ptr)
+for i in range(reps): step(i)
 ms = dut.timer_stop() / reps
 cells = x.size
+if with_list or fused: print("detections {found, stored}:", cnt.download(np.uint32, 2).tolist())
 print(f"rd2d nr={nr} nd={nd} ch={n_ch}: {ms*1e3:.1f} us/batch  {cells/ms/1e6:.1f} Gcells/s  {cells*28/ms/1e9:.2f} TB/s (28 B/cell algorithmic)")
