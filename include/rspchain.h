@@ -110,6 +110,7 @@ enum { RSP_TRIM_FLOOR = 0, RSP_TRIM_HALF_UP = 1, RSP_TRIM_CONVERGENT = 2 };
 enum { RSP_ALG_CA = 0, RSP_ALG_GOS = 1, RSP_ALG_GOSCA = 2 };
 enum { RSP_EDGE_ZERO = 0, RSP_EDGE_WRAP = 1 };
 enum { RSP_MAG_SQR = 0, RSP_MAG_LOG2 = 1, RSP_MAG_JPL = 2 }; /* 2: FftMagCfarChainTester.scala:84 */
+enum { RSP_WINDOW_NONE = 0, RSP_WINDOW_HANN = 1, RSP_WINDOW_HAMMING = 2, RSP_WINDOW_BLACKMAN = 3 };
 enum { RSP_MODE_CA = 0, RSP_MODE_GO = 1, RSP_MODE_SO = 2, RSP_MODE_CASH = 3 }; /* Tester:86-92 */
 
 /* Sample type streamed through the chain.  FIXED16 is the reference's
@@ -135,7 +136,9 @@ typedef struct rsp_chain_params {
   int32_t dopplerPoints; /* 0 = 1-D chain; else slow-time FFT size of the 2-D range-Doppler chain */
   int32_t refDoppler;    /* 2-D CFAR training / guard half-widths along Doppler */
   int32_t guardDoppler;
-  int32_t reserved[8];
+  int32_t window;        /* RSP_WINDOW_*: pre-FFT window over fast time (range); SURVEY 8f-n4, no reference item */
+  int32_t windowDoppler; /* RSP_WINDOW_*: 2-D chain, window over slow time */
+  int32_t reserved[6];
 } rsp_chain_params;
 
 typedef struct rsp_chain rsp_chain;
@@ -173,7 +176,12 @@ int rsp_chain_check_regs(rsp_chain* c);
  * beat of every frame, Tester:137), collect fftSize output words per frame
  * (Tester:145-151).  Host buffers; synchronous.  Beat = 4 bytes (FIXED16) or
  * 8 bytes (F32).  For the 2-D chain a "frame" is one channel's
- * dopplerPoints x fftSize map, [doppler][range] row-major. */
+ * dopplerPoints x fftSize map, [doppler][range] row-major.
+ * CFARParams.sendCut = true (FftMagCfarChain.scala:107) widens the output beat to 64 bits: TWO
+ * words per cell, {the word described above, the cell under test} (FIXED16: the magnitude as a
+ * sign-extended integer; F32: its fp32 bits) -- out_words then holds 2 x fftSize words per frame.
+ * FFTParams.useBitReverse = false: the FFT block streams its result in bit-reversed order and the
+ * blocks behind it work on that order; position p of a frame then refers to bin bitrev(p). */
 int rsp_chain_process(rsp_chain* c, const void* in_beats, size_t n_frames, uint32_t* out_words);
 /* Same with buffers already resident in HBM; asynchronous on the chain's stream. */
 int rsp_chain_process_device(rsp_chain* c, const void* d_in_beats, size_t n_frames,

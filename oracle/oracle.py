@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "librsp_oracle.so")
 
 TRIM_FLOOR, TRIM_HALF_UP, TRIM_CONVERGENT = 0, 1, 2
+WIN_NONE, WIN_HANN, WIN_HAMMING, WIN_BLACKMAN = 0, 1, 2, 3
 MAG_SQR, MAG_LOG2, MAG_JPL = 0, 1, 2
 CFAR_CA, CFAR_GO, CFAR_SO, CFAR_CASH = 0, 1, 2, 3
 EDGE_ZERO, EDGE_WRAP = 0, 1
@@ -26,20 +27,22 @@ class OrcCfg(C.Structure):
         "log2n", "trim", "mag_mode", "bp_data", "bp_log", "log2_lut_width", "bp_in",
         "bp_thr", "w_thr", "bp_scaler")] + [("scaler", C.c_uint32)] + [(n, C.c_int32) for n in (
             "linear", "div_sum", "peak_grouping", "algorithm", "cfar_mode", "ref_window",
-            "guard_window", "index_lagg", "index_lead", "sub_window", "edge")]
+            "guard_window", "index_lagg", "index_lead", "sub_window", "edge")] + [
+                ("keep_lsb_mask", C.c_uint32), ("expand_mask", C.c_uint32), ("no_bit_reverse", C.c_int32),
+                ("send_cut", C.c_int32), ("window", C.c_int32)]
 
 
 class OrcFCfg(C.Structure):
     _fields_ = [("log2n", C.c_int32), ("mag_mode", C.c_int32), ("scaler", C.c_double)] + [
         (n, C.c_int32) for n in ("linear", "div_sum", "peak_grouping", "algorithm", "cfar_mode",
                                  "ref_window", "guard_window", "index_lagg", "index_lead", "edge",
-                                 "sub_window")]
+                                 "sub_window", "no_bit_reverse", "window")]
 
 
 class OrcRdCfg(C.Structure):
     _fields_ = [("log2nr", C.c_int32), ("log2nd", C.c_int32), ("mag_mode", C.c_int32),
                 ("scaler", C.c_double)] + [(n, C.c_int32) for n in (
-                    "ref_r", "ref_d", "guard_r", "guard_d", "edge")]
+                    "ref_r", "ref_d", "guard_r", "guard_d", "edge", "window_r", "window_d")]
 
 
 class OrcStimCfg(C.Structure):
@@ -80,6 +83,10 @@ def lib():
         L.orc_pack_out.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
         L.orc_twiddles_q14.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
         L.orc_fft_fixed.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_fft_fixed_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int,
+                                       C.c_void_p, C.c_void_p]
+        L.orc_window_coeff.restype = C.c_double
+        L.orc_window_coeff.argtypes = [C.c_int, C.c_int, C.c_int]
         L.orc_mag_fixed.restype = C.c_int32
         L.orc_mag_fixed.argtypes = [C.c_int16, C.c_int16, P(OrcCfg)]
         L.orc_cfar_fixed.argtypes = [C.c_void_p, P(OrcCfg), C.c_void_p, C.c_void_p]
@@ -109,7 +116,7 @@ def default_cfg(**kw) -> OrcCfg:
                log2_lut_width=9, bp_in=12, bp_thr=12, w_thr=16, bp_scaler=12,
                scaler=int(3.5 * 4096), linear=1, div_sum=5, peak_grouping=0, algorithm=0,
                cfar_mode=CFAR_GO, ref_window=32, guard_window=4, index_lagg=0, index_lead=0,
-               sub_window=0, edge=EDGE_ZERO)
+               sub_window=0, edge=EDGE_ZERO, keep_lsb_mask=0, expand_mask=0, no_bit_reverse=0, send_cut=0, window=0)
     for k, v in kw.items():
         setattr(c, k, v)
     return c
@@ -118,7 +125,7 @@ def default_cfg(**kw) -> OrcCfg:
 def default_fcfg(**kw) -> OrcFCfg:
     c = OrcFCfg(log2n=12, mag_mode=MAG_JPL, scaler=3.5, linear=1, div_sum=5, peak_grouping=0,
                 algorithm=0, cfar_mode=CFAR_CA, ref_window=32, guard_window=4, index_lagg=0,
-                index_lead=0, edge=EDGE_ZERO, sub_window=0)
+                index_lead=0, edge=EDGE_ZERO, sub_window=0, no_bit_reverse=0, window=0)
     for k, v in kw.items():
         setattr(c, k, v)
     return c
@@ -138,7 +145,7 @@ def twiddles_q14(log2n: int):
     return wr, wi
 
 
-def fft_fixed(re, im, trim=TRIM_CONVERGENT):
+def fft_fixed(re, im, trim=TRIM_CONVERGENT, keep_lsb_mask=0, expand_mask=0, no_bit_reverse=0):
     re = np.ascontiguousarray(re, np.int16)
     im = np.ascontiguousarray(im, np.int16)
     n = re.size
@@ -146,7 +153,7 @@ def fft_fixed(re, im, trim=TRIM_CONVERGENT):
     assert 1 << log2n == n
     orr = np.zeros(n, np.int16)
     oi = np.zeros(n, np.int16)
-    lib().orc_fft_fixed(_p(re), _p(im), log2n, trim, _p(orr), _p(oi))
+    lib().orc_fft_fixed_ex(_p(re), _p(im), log2n, trim, keep_lsb_mask, expand_mask, no_bit_reverse, _p(orr), _p(oi))
     return orr, oi
 
 
@@ -171,7 +178,7 @@ def chain_fixed(in_beats, cfg: OrcCfg) -> np.ndarray:
     beats = np.ascontiguousarray(in_beats, np.uint32).ravel()
     n = 1 << cfg.log2n
     assert beats.size % n == 0
-    out = np.zeros(beats.size, np.uint32)
+    out = np.zeros(beats.size * (2 if cfg.send_cut else 1), np.uint32)   # sendCut: {word, cut} per cell
     lib().orc_chain_fixed(_p(beats), beats.size // n, C.byref(cfg), _p(out))
     return out
 

@@ -61,8 +61,6 @@ static int64_t trim_shift(int64_t x, int n, int trim) {
   }
 }
 
-/* dataWidth = 16 (Chain:79): results wrap like a 16-bit register. */
-static int16_t wrap16(int64_t x) { return (int16_t)(uint16_t)(x & 0xFFFF); }
 
 /* twiddleWidth = 16 (Chain:80), BP = 14: W_N^k = exp(-2 pi i k / N), rounded to
  * nearest (BUILD-DEFINED rounding of the ROM contents). */
@@ -95,42 +93,75 @@ static unsigned bitrev(unsigned x, int bits) {
  * bit, (a-b)*W by 15 bits (14 twiddle fraction bits + the dropped LSB).
  * The bit-reversed result is reordered (useBitReverse = true, Chain:82).
  */
-void orc_fft_fixed(const int16_t* re_in, const int16_t* im_in, int log2n, int trim,
-                   int16_t* re_out, int16_t* im_out) {
+static int64_t wrap_bits(int64_t x, int bits) { /* two's-complement wrap to `bits` bits */
+  uint64_t m = ((uint64_t)1 << bits) - 1u, v = (uint64_t)x & m;
+  return (v >> (bits - 1)) ? (int64_t)(v | ~m) : (int64_t)v;
+}
+
+void orc_fft_fixed_ex(const int16_t* re_in, const int16_t* im_in, int log2n, int trim,
+                      uint32_t keep_lsb_mask, uint32_t expand_mask, int no_bit_reverse,
+                      int16_t* re_out, int16_t* im_out) {
   int n = 1 << log2n;
-  int16_t* xr = (int16_t*)malloc(sizeof(int16_t) * (size_t)n);
-  int16_t* xi = (int16_t*)malloc(sizeof(int16_t) * (size_t)n);
+  int64_t* xr = (int64_t*)malloc(sizeof(int64_t) * (size_t)n);
+  int64_t* xi = (int64_t*)malloc(sizeof(int64_t) * (size_t)n);
   int16_t* wr = (int16_t*)malloc(sizeof(int16_t) * (size_t)(n / 2 + 1));
   int16_t* wi = (int16_t*)malloc(sizeof(int16_t) * (size_t)(n / 2 + 1));
-  memcpy(xr, re_in, sizeof(int16_t) * (size_t)n);
-  memcpy(xi, im_in, sizeof(int16_t) * (size_t)n);
+  for (int i = 0; i < n; i++) {
+    xr[i] = re_in[i];
+    xi[i] = im_in[i];
+  }
   orc_twiddles_q14(log2n, wr, wi);
+  int w = 16, growth = 0; /* dataWidth = 16 (Chain:79) + one bit per expanding stage so far */
   for (int s = 0; s < log2n; s++) {
     int half = n >> (s + 1);
+    int grow = (int)((expand_mask >> s) & 1u);
+    int lsb = !grow && ((keep_lsb_mask >> s) & 1u);
+    /* result formats: grow -> w+1 bits, nothing trimmed; keep MSB -> trim 1 bit, w bits;
+     * keep LSB -> no trim, wrapped to w bits.  The product carries 14 twiddle fraction bits more. */
+    int sh_sum = (grow || lsb) ? 0 : 1, sh_prod = 14 + sh_sum, wout = w + grow;
     for (int base = 0; base < n; base += 2 * half) {
       for (int j = 0; j < half; j++) {
         int a = base + j, b = a + half;
         int k = j << s; /* W_{2*half}^j == W_N^(j * 2^s) */
-        int64_t sr = (int64_t)xr[a] + xr[b], si = (int64_t)xi[a] + xi[b];
-        int64_t dr = (int64_t)xr[a] - xr[b], di = (int64_t)xi[a] - xi[b];
+        int64_t sr = xr[a] + xr[b], si = xi[a] + xi[b];
+        int64_t dr = xr[a] - xr[b], di = xi[a] - xi[b];
         int64_t pr = dr * wr[k] - di * wi[k];
         int64_t pi = dr * wi[k] + di * wr[k];
-        xr[a] = wrap16(trim_shift(sr, 1, trim));
-        xi[a] = wrap16(trim_shift(si, 1, trim));
-        xr[b] = wrap16(trim_shift(pr, 15, trim));
-        xi[b] = wrap16(trim_shift(pi, 15, trim));
+        xr[a] = wrap_bits(trim_shift(sr, sh_sum, trim), wout);
+        xi[a] = wrap_bits(trim_shift(si, sh_sum, trim), wout);
+        xr[b] = wrap_bits(trim_shift(pr, sh_prod, trim), wout);
+        xi[b] = wrap_bits(trim_shift(pi, sh_prod, trim), wout);
       }
     }
+    w = wout;
+    growth += grow;
   }
   for (int k = 0; k < n; k++) {
-    unsigned p = bitrev((unsigned)k, log2n);
-    re_out[k] = xr[p];
-    im_out[k] = xi[p];
+    unsigned p = no_bit_reverse ? (unsigned)k : bitrev((unsigned)k, log2n);
+    /* position k of the output stream holds element p of the in-place result = bin bitrev(p) */
+    re_out[k] = (int16_t)(xr[p] >> growth);
+    im_out[k] = (int16_t)(xi[p] >> growth);
   }
   free(xr);
   free(xi);
   free(wr);
   free(wi);
+}
+
+void orc_fft_fixed(const int16_t* re_in, const int16_t* im_in, int log2n, int trim,
+                   int16_t* re_out, int16_t* im_out) {
+  orc_fft_fixed_ex(re_in, im_in, log2n, trim, 0u, 0u, 0, re_out, im_out);
+}
+
+/* pre-FFT window (no reference item): w[i], i < n, symmetric ("periodic = false") */
+double orc_window_coeff(int window, int i, int n) {
+  double x = 2.0 * M_PI * (double)i / (double)(n - 1);
+  switch (window) {
+    case ORC_WIN_HANN: return 0.5 - 0.5 * cos(x);
+    case ORC_WIN_HAMMING: return 0.54 - 0.46 * cos(x);
+    case ORC_WIN_BLACKMAN: return 0.42 - 0.5 * cos(x) + 0.08 * cos(2.0 * x);
+    default: return 1.0;
+  }
 }
 
 /* ------------------------------------------------------------------ fixed-point magnitude */
@@ -288,14 +319,32 @@ void orc_chain_fixed(const uint32_t* in_beats, size_t n_frames, const orc_cfg* c
   int16_t* re = (int16_t*)malloc(sizeof(int16_t) * (size_t)n * 4);
   int16_t *im = re + n, *fr = re + 2 * n, *fi = re + 3 * n;
   int32_t* mag = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+  uint32_t* words = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)n);
   for (size_t f = 0; f < n_frames; f++) {
-    for (int i = 0; i < n; i++) orc_unpack_iq(in_beats[f * (size_t)n + (size_t)i], &re[i], &im[i]);
-    orc_fft_fixed(re, im, c->log2n, c->trim, fr, fi);
+    for (int i = 0; i < n; i++) {
+      orc_unpack_iq(in_beats[f * (size_t)n + (size_t)i], &re[i], &im[i]);
+      if (c->window != ORC_WIN_NONE) {
+        /* BUILD-DEFINED: coefficient rounded to Q1.15 (32767 = 1 - 2^-15), product rounded half-up to 16 bits */
+        int32_t wq = (int32_t)lround(orc_window_coeff(c->window, i, n) * 32767.0);
+        re[i] = (int16_t)(((int32_t)re[i] * wq + (1 << 14)) >> 15);
+        im[i] = (int16_t)(((int32_t)im[i] * wq + (1 << 14)) >> 15);
+      }
+    }
+    orc_fft_fixed_ex(re, im, c->log2n, c->trim, c->keep_lsb_mask, c->expand_mask, c->no_bit_reverse, fr, fi);
     for (int i = 0; i < n; i++) mag[i] = orc_mag_fixed(fr[i], fi[i], c);
-    orc_cfar_fixed(mag, c, out_words + f * (size_t)n, NULL);
+    if (!c->send_cut) {
+      orc_cfar_fixed(mag, c, out_words + f * (size_t)n, NULL);
+    } else { /* 64-bit beat: low word = the sendCut = false word, high word = the cell under test */
+      orc_cfar_fixed(mag, c, words, NULL);
+      for (int i = 0; i < n; i++) {
+        out_words[2 * (f * (size_t)n + (size_t)i)] = words[i];
+        out_words[2 * (f * (size_t)n + (size_t)i) + 1] = (uint32_t)mag[i];
+      }
+    }
   }
   free(re);
   free(mag);
+  free(words);
 }
 
 /* ------------------------------------------------------------------ float64 path */
@@ -453,8 +502,17 @@ void orc_chain_f32in(const float* in, size_t n_frames, const orc_fcfg* c, double
     for (long f = 0; f < (long)n_frames; f++) {
       const float* src = in + 2 * (size_t)f * (size_t)n;
       for (int i = 0; i < 2 * n; i++) x[i] = (double)src[i];
+      if (c->window != ORC_WIN_NONE)
+        for (int i = 0; i < n; i++) {
+          double wv = (double)(float)orc_window_coeff(c->window, i, n); /* fp32 coefficient table, as the device holds */
+          x[2 * i] *= wv;
+          x[2 * i + 1] *= wv;
+        }
       fft_f64_strided(x, 1, c->log2n, tw, y);
-      for (int i = 0; i < n; i++) m[i] = orc_mag_f64(y[2 * i], y[2 * i + 1], c->mag_mode);
+      for (int i = 0; i < n; i++) {
+        int p = c->no_bit_reverse ? (int)bitrev((unsigned)i, c->log2n) : i; /* position i holds bin p */
+        m[i] = orc_mag_f64(y[2 * p], y[2 * p + 1], c->mag_mode);
+      }
       if (mag_out) memcpy(mag_out + (size_t)f * (size_t)n, m, sizeof(double) * (size_t)n);
       orc_cfar_f64(m, c, thr + (size_t)f * (size_t)n, peak + (size_t)f * (size_t)n,
                    margin ? margin + (size_t)f * (size_t)n : NULL);
@@ -496,6 +554,15 @@ void orc_rd_f32in(const float* in, size_t n_ch, const orc_rdcfg* c, double* thr,
     double* sat = (double*)calloc((size_t)(er + 1) * (size_t)(ed + 1), sizeof(double));
     const float* src = in + 2 * map * (size_t)ch;
     for (size_t i = 0; i < 2 * map; i++) a[i] = (double)src[i];
+    if (c->window_r != ORC_WIN_NONE || c->window_d != ORC_WIN_NONE)
+      for (int d = 0; d < nd; d++) {
+        double wd = (double)(float)orc_window_coeff(c->window_d, d, nd);
+        for (int r = 0; r < nr; r++) {
+          double wv = wd * (double)(float)orc_window_coeff(c->window_r, r, nr);
+          a[2 * ((size_t)d * (size_t)nr + (size_t)r)] *= wv;
+          a[2 * ((size_t)d * (size_t)nr + (size_t)r) + 1] *= wv;
+        }
+      }
     for (int d = 0; d < nd; d++) /* range FFT along r (contiguous) */
       fft_f64_strided(a + 2 * (size_t)d * (size_t)nr, 1, c->log2nr, twr, b + 2 * (size_t)d * (size_t)nr);
     for (int r = 0; r < nr; r++) { /* Doppler FFT along d (stride nr) */

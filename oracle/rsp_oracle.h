@@ -65,7 +65,17 @@ typedef struct orc_cfg {
   int32_t index_lead;     /* CFAR CSR 0x28 (Tester:126)                             */
   int32_t sub_window;     /* CFAR CSR 0x2C (Tester:131); CASH only                  */
   int32_t edge;           /* BUILD-DEFINED frame-edge policy                        */
+  /* elaboration options every reference configuration leaves at the value 0 here   */
+  uint32_t keep_lsb_mask; /* bit s: FFTParams keepMSBorLSB(s) = false (FftMagCfarChain:87) */
+  uint32_t expand_mask;   /* bit s: FFTParams expandLogic(s) = 1 (FftMagCfarChain:86)      */
+  int32_t no_bit_reverse; /* 1: FFTParams useBitReverse = false (FftMagCfarChain:82)       */
+  int32_t send_cut;       /* 1: CFARParams sendCut = true (FftMagCfarChain:107)            */
+  int32_t window;         /* pre-FFT window (no reference item): ORC_WIN_*   */
 } orc_cfg;
+
+/* pre-FFT window functions (build extension); coefficients Q1.15 / double */
+enum { ORC_WIN_NONE = 0, ORC_WIN_HANN = 1, ORC_WIN_HAMMING = 2, ORC_WIN_BLACKMAN = 3 };
+double orc_window_coeff(int window, int i, int n);
 
 /* ---- wire formats --------------------------------------------------------- */
 /* RspChainTesterUtils.scala:105-109: data[31:16] = re, data[15:0] = im, int16. */
@@ -84,11 +94,24 @@ void orc_twiddles_q14(int log2n, int16_t* wr, int16_t* wi);
  * (useBitReverse = true, FftMagCfarChain.scala:82). */
 void orc_fft_fixed(const int16_t* re_in, const int16_t* im_in, int log2n, int trim,
                    int16_t* re_out, int16_t* im_out);
+/* The same with the per-stage options of FFTParams.fixed (FftMagCfarChain.scala:82,86-87), all
+ * BUILD-DEFINED (docs/FIXED_POINT_SPEC.md section 3):
+ *   expandLogic(s) = 1   stage s keeps its (w+1)-bit results: the word grows by one bit, nothing is
+ *                        rounded away at that stage;
+ *   keepMSBorLSB(s) = false (expandLogic(s) = 0)  the (w+1)-bit result is cut back to w bits by dropping
+ *                        its MSB: no halving at that stage, overflow wraps;
+ *   the 2 x 16-bit stream to the magnitude block (beatBytes = 4) carries the 16 most significant bits
+ *   of a grown word (floor shift by the number of expanding stages);
+ *   useBitReverse = false: the frame leaves in bit-reversed order (position p holds bin bitrev(p)). */
+void orc_fft_fixed_ex(const int16_t* re_in, const int16_t* im_in, int log2n, int trim,
+                      uint32_t keep_lsb_mask, uint32_t expand_mask, int no_bit_reverse,
+                      int16_t* re_out, int16_t* im_out);
 int32_t orc_mag_fixed(int16_t re, int16_t im, const orc_cfg* c);
 /* One frame of magnitudes -> N output words. */
 void orc_cfar_fixed(const int32_t* mag, const orc_cfg* c, uint32_t* out_words,
                     int32_t* thr_out /* may be NULL */);
-/* Whole chain, n_frames frames of 2^log2n beats each. */
+/* Whole chain, n_frames frames of 2^log2n beats each.  With c->send_cut the output beat is 64 bits,
+ * two words per cell: {word as above, cut} (BUILD-DEFINED packing of the wider CFAR beat). */
 void orc_chain_fixed(const uint32_t* in_beats, size_t n_frames, const orc_cfg* c,
                      uint32_t* out_words);
 
@@ -108,6 +131,8 @@ typedef struct orc_fcfg {
   int32_t index_lead;
   int32_t edge;
   int32_t sub_window; /* CASH only */
+  int32_t no_bit_reverse;
+  int32_t window;
 } orc_fcfg;
 
 /* Forward FFT with the same net 1/N scaling, in float64. interleaved re,im. */
@@ -135,6 +160,7 @@ typedef struct orc_rdcfg {
   double scaler;
   int32_t ref_r, ref_d, guard_r, guard_d;
   int32_t edge;
+  int32_t window_r, window_d; /* ORC_WIN_*: windows over fast / slow time (build extension) */
 } orc_rdcfg;
 void orc_rd_f32in(const float* in, size_t n_ch, const orc_rdcfg* c, double* thr, uint8_t* peak,
                   double* margin, double* mag_out /* may be NULL */, int n_threads);

@@ -51,7 +51,7 @@ class ChainParamsC(C.Structure):
                 ("fftAddress", AddressSetC), ("magAddress", AddressSetC), ("cfarAddress", AddressSetC),
                 ("beatBytes", C.c_int32), ("dtype", C.c_int32), ("device", C.c_int32),
                 ("dopplerPoints", C.c_int32), ("refDoppler", C.c_int32), ("guardDoppler", C.c_int32),
-                ("reserved", C.c_int32 * 8)]
+                ("window", C.c_int32), ("windowDoppler", C.c_int32), ("reserved", C.c_int32 * 6)]
 
 
 class PlfgParamsC(C.Structure):

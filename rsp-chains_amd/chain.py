@@ -30,6 +30,7 @@ CACFARType, GOSCFARType, GOSCACFARType = "CACFARType", "GOSCFARType", "GOSCACFAR
 _ALG = {CACFARType: 0, GOSCFARType: 1, GOSCACFARType: 2}
 _TRIM = {"RoundDown": 0, "Floor": 0, "RoundHalfUp": 1, "Convergent": 2}
 _EDGE = {"zero": 0, "wrap": 1}
+_WINDOW = {None: 0, "none": 0, "hann": 1, "hamming": 2, "blackman": 3}   # RSP_WINDOW_*
 FIXED16, F32 = 0, 1
 
 
@@ -156,6 +157,9 @@ class FftMagCfarVanillaParameters:
     dopplerPoints: int = 0
     refDoppler: int = 0
     guardDoppler: int = 0
+    # pre-FFT window functions (the reference has none): over fast time / over slow time (2-D chain)
+    window: Optional[str] = None
+    windowDoppler: Optional[str] = None
 
     def to_c(self) -> N.ChainParamsC:
         p = N.ChainParamsC()
@@ -192,6 +196,9 @@ class FftMagCfarVanillaParameters:
             getattr(p, name).base, getattr(p, name).mask = a.base, a.mask
         p.beatBytes, p.dtype, p.device = self.beatBytes, self.dtype, self.device
         p.dopplerPoints, p.refDoppler, p.guardDoppler = self.dopplerPoints, self.refDoppler, self.guardDoppler
+        if self.window not in _WINDOW or self.windowDoppler not in _WINDOW:
+            raise ValueError(f"requirement failed: window {self.window!r} / {self.windowDoppler!r}")
+        p.window, p.windowDoppler = _WINDOW[self.window], _WINDOW[self.windowDoppler]
         return p
 
 
@@ -334,12 +341,13 @@ class FftMagCfarChainVanilla:
         collect fftSize output words per frame (Tester:145-151)."""
         a = self._as_beats(beats)
         n = self.frameCells
-        out = np.empty(a.size, np.uint32)
+        cut = bool(self.params.cfarParams.sendCut)   # 64-bit output beat: {word, cut} per cell
+        out = np.empty(a.size * (2 if cut else 1), np.uint32)
         _check(self._lib.rsp_chain_process(self._h, a.ctypes.data_as(C.c_void_p), a.size // n,
                                            out.ctypes.data_as(C.c_void_p)))
         if self.params.dopplerPoints:
             return out.reshape(-1, self.params.dopplerPoints, self.fftSize)
-        return out.reshape(-1, n)
+        return out.reshape(-1, n, 2) if cut else out.reshape(-1, n)
 
     def detections(self, beats, cap: int = 1 << 20):
         """Host-buffer convenience: (sorted detection records, number of peaks found).  Complete: frames

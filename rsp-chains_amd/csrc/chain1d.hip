@@ -201,6 +201,14 @@ __device__ __forceinline__ void front_end(const void* __restrict__ in, uint32_t 
         const size_t eo = (size_t)(elem_index<M, LO, W>(0, e) - elem_index<M, LO, W>(0, 0)) * 8u;
         x[e] = *reinterpret_cast<const f32x2*>(gbase + (size_t)voff + eo);
       }
+      if (rg.window) {  // pre-FFT window (build extension): one fp32 coefficient per sample
+        const float* wt = reinterpret_cast<const float*>(rg.window) + elem_index<M, LO, W>(tau, 0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float wv = wt[elem_index<M, LO, W>(0, e) - elem_index<M, LO, W>(0, 0)];
+          x[e] = x[e] * f32x2{wv, wv};
+        }
+      }
     }
     STAMP(1);
     if (!ABL(0)) pass_f32<M, 0>(x, twb.template get<0>());
@@ -292,6 +300,15 @@ __device__ __forceinline__ void front_end(const void* __restrict__ in, uint32_t 
         xr[e] = (int)(short)(b >> 16);
         xi[e] = (int)(short)(b & 0xffffu);
       }
+      if (rg.window) {  // Q1.15 coefficient, product rounded half-up back to 16 bits (spec section 2.1)
+        const int16_t* wt = reinterpret_cast<const int16_t*>(rg.window) + elem_index<M, LO, W>(tau, 0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int wq = wt[elem_index<M, LO, W>(0, e) - elem_index<M, LO, W>(0, 0)];
+          xr[e] = (int)(short)((xr[e] * wq + (1 << 14)) >> 15);
+          xi[e] = (int)(short)((xi[e] * wq + (1 << 14)) >> 15);
+        }
+      }
     }
     // twiddle ROM -> LDS once per workgroup (the sample loads above are already in flight)
     for (int i = threadIdx.x; i < N / 2; i += wg_size(M)) rom[i] = twq[i];
@@ -330,8 +347,50 @@ __device__ __forceinline__ void front_end(const void* __restrict__ in, uint32_t 
       if constexpr (NP > 2) exchange(std::integral_constant<int, 2>{});
       if constexpr (NP > 3) exchange(std::integral_constant<int, 3>{});
     };
+    // expandLogic / keepMSBorLSB = false somewhere: generic stages, 8-byte exchange slots (words grow past 16 bits)
+    auto run_opt = [&]() {
+      uint2* wbuf = reinterpret_cast<uint2*>(fbase);
+      pass_fx_opt<M, 0>(xr, xi, tau, rom, rg);
+      auto exchange = [&](auto pc) {
+        constexpr int P = decltype(pc)::value;
+        constexpr int W0 = plan_w(M, P - 1), LO0 = plan_lo(M, P - 1);
+        constexpr int W1 = plan_w(M, P), LO1 = plan_lo(M, P);
+        constexpr bool LAST = P == NP - 1;
+#pragma unroll
+        for (int g = 0; g < (16 >> W0); ++g) {
+          uint2* b0 = wbuf + slot_base<M, LO0, W0, LAST>(tau, g);
+#pragma unroll
+          for (int r = 0; r < (1 << W0); ++r) {
+            const int e = g * (1 << W0) + r;
+            b0[slot_delta<M, LO0, W0>(r)] = make_uint2((uint32_t)xr[e], (uint32_t)xi[e]);
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < (16 >> W1); ++g) {
+          const uint2* b1 = wbuf + slot_base<M, LO1, W1, LAST>(tau, g);
+#pragma unroll
+          for (int r = 0; r < (1 << W1); ++r) {
+            const uint2 b = b1[slot_delta<M, LO1, W1>(r)];
+            xr[g * (1 << W1) + r] = (int)b.x;
+            xi[g * (1 << W1) + r] = (int)b.y;
+          }
+        }
+        pass_fx_opt<M, P>(xr, xi, tau, rom, rg);
+      };
+      exchange(std::integral_constant<int, 1>{});
+      if constexpr (NP > 2) exchange(std::integral_constant<int, 2>{});
+      if constexpr (NP > 3) exchange(std::integral_constant<int, 3>{});
+      // the 2 x 16-bit stream to the magnitude block carries the 16 MSBs of a grown word
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        xr[e] = (int)(short)(xr[e] >> rg.growth);
+        xi[e] = (int)(short)(xi[e] >> rg.growth);
+      }
+    };
     // convergent (the default trim) has a 3-op closed form; floor / half-up share the generic one
-    if (rg.trim_conv) run(std::true_type{});
+    if (rg.keep_lsb_mask | rg.expand_mask) run_opt();
+    else if (rg.trim_conv) run(std::true_type{});
     else run(std::false_type{});
     if (rg.mag_mode == 2) {
 #pragma unroll
@@ -347,10 +406,19 @@ __device__ __forceinline__ void front_end(const void* __restrict__ in, uint32_t 
 // magnitudes -> LDS in natural bin order, cell x at slot x' + PM (x' >> 4), x' = x + moff (moff a multiple
 // of 16): PM = 1 is the FFT image's padding, PM = 4 the 16-byte-aligned one of the quad tail
 template <int M, typename V, int PM = 1>
-__device__ __forceinline__ void write_mag(V* mag, int moff, int tau, const V (&mg)[16]) {
+__device__ __forceinline__ void write_mag(V* mag, int moff, int tau, const V (&mg)[16], bool rev_order = false) {
   constexpr int T = threads_per_frame(M), NP = plan_np(M), WL = plan_w(M, NP - 1);
 #pragma unroll
   for (int g = 0; g < (16 >> WL); ++g) {
+    if (rev_order) {
+      // useBitReverse = false: bin b sits at stream position bitrev(b) = (bitrev(g T + tau) << WL) | p:
+      // the thread's 2^WL values of this group are consecutive positions inside one 16-run
+      const int x = (int)((__brev((unsigned)(g * T + tau)) >> (32 - (M - WL))) << WL) + moff;
+      V* mb = mag + x + PM * (x >> 4);
+#pragma unroll
+      for (int p = 0; p < (1 << WL); ++p) mb[p] = mg[g * (1 << WL) + p];
+      continue;
+    }
     // bin = (q << (M-WL)) | (g T + tau) (fft_lds.hpp, last pass): q << (M-WL) is a multiple of 16, so its
     // slot offset is constant, and consecutive lanes write consecutive slots
     const int x = g * T + tau + moff;
@@ -364,13 +432,17 @@ __device__ __forceinline__ void write_mag(V* mag, int moff, int tau, const V (&m
 }
 
 // dense words to HBM (256 B per wave-instruction) + optional per-frame detection slots
-template <int M>
+template <int M, typename V>
 __device__ __forceinline__ void emit_words(const uint32_t (&word)[16], uint32_t* __restrict__ out,
                                            uint32_t frame, bool live, int tau, uint32_t* det_cnt,
                                            uint2* det_stage, uint32_t* __restrict__ fcount,
-                                           uint2* __restrict__ fdet) {
+                                           uint2* __restrict__ fdet, const V* cut_lds = nullptr, int cut_stride = 0) {
   constexpr int N = 1 << M, T = threads_per_frame(M);
-  if (live && out) {
+  if (live && out && cut_lds) {  // sendCut = true: 64-bit beat {word, cut}; cut of cell tau + T j at cut_lds[cut_stride j]
+    uint2* obase = reinterpret_cast<uint2*>(out) + (size_t)frame * N + tau;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) obase[T * j] = make_uint2(word[j], __builtin_bit_cast(uint32_t, cut_lds[cut_stride * j]));
+  } else if (live && out) {
     char* obase = reinterpret_cast<char*>(out);
     const uint32_t ooff = (frame * (uint32_t)N + (uint32_t)tau) * 4u;
 #pragma unroll
@@ -434,7 +506,7 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
   uint2* det_stage = reinterpret_cast<uint2*>(fbase + L::DET_OFF + 8);
   const bool wrap = rg.edge != 0;
   __syncthreads();  // every thread is done reading the FFT image this overlays
-  write_mag<M, V>(mag, 16, tau, mg);
+  write_mag<M, V>(mag, 16, tau, mg, rg.rev_order != 0);
   if (tau == 0) *det_cnt = 0u;
   __syncthreads();
 
@@ -600,7 +672,8 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
       else cells(I3{}, std::false_type{});
     }
   }
-  emit_words<M>(word, out, frame, live, tau, det_cnt, det_stage, fcount, fdet);
+  emit_words<M, V>(word, out, frame, live, tau, det_cnt, det_stage, fcount, fdet,
+                   rg.send_cut ? mag + mag_slot(tau) : nullptr, T + T / 16);
 }
 
 // ---------------------------------------------------------------- quad tail (the default CA/GO/SO path)
@@ -634,6 +707,9 @@ struct QuadLds {
   static constexpr int BYTES = ((CFAR_BYTES > FFT_BYTES ? CFAR_BYTES : FFT_BYTES) + 15) & ~15;
   static constexpr int ROM_BYTES = 4 * (N / 2);
 };
+
+__device__ __forceinline__ uint32_t bits_of(float v) { return __float_as_uint(v); }
+__device__ __forceinline__ uint32_t bits_of(int v) { return (uint32_t)v; }
 
 template <typename V> struct Vec4;
 template <> struct Vec4<float> { typedef float type __attribute__((ext_vector_type(4))); };
@@ -714,11 +790,20 @@ chain1d_quad_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uin
   __syncthreads();  // every thread is done reading the FFT image this overlays
   {  // magnitudes to LDS in natural bin order: register (g, p) holds bin (bitrev(p) << (M - WL)) | (g T + tau)
     constexpr int NP = plan_np(M), WL = plan_w(M, NP - 1);
+    if (rg.rev_order) {  // useBitReverse = false: bin b at stream position bitrev(b) = (bitrev(g T + tau) << WL) | p
 #pragma unroll
-    for (int g = 0; g < (16 >> WL); ++g) {
-      V* mb = mag + g * T + tau;
+      for (int g = 0; g < (16 >> WL); ++g) {
+        V* mb = mag + ((__brev((unsigned)(g * T + tau)) >> (32 - (M - WL))) << WL);
 #pragma unroll
-      for (int p = 0; p < (1 << WL); ++p) mb[bitrev_c(p, WL) << (M - WL)] = mg[g * (1 << WL) + p];
+        for (int p = 0; p < (1 << WL); ++p) mb[p] = mg[g * (1 << WL) + p];
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < (16 >> WL); ++g) {
+        V* mb = mag + g * T + tau;
+#pragma unroll
+        for (int p = 0; p < (1 << WL); ++p) mb[bitrev_c(p, WL) << (M - WL)] = mg[g * (1 << WL) + p];
+      }
     }
   }
   if (tau == 0) {
@@ -923,7 +1008,17 @@ chain1d_quad_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uin
 
   STAMP(10);
   // ---- dense words: one 16-byte store per quad (1 KiB per wave-instruction) ----
-  if (live && out) {
+  if (live && out && rg.send_cut) {  // sendCut = true: 64-bit beat {word, cut}, two 16-byte stores per quad
+    char* obase = reinterpret_cast<char*>(out) + ((size_t)frame * N + 4u * (size_t)tau) * 8u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const V c0 = mq[e][0], c1 = mq[e][1], c2 = mq[e][2], c3 = mq[e][3];
+      const u32x4 lo4 = {word[4 * e], bits_of(c0), word[4 * e + 1], bits_of(c1)};
+      const u32x4 hi4 = {word[4 * e + 2], bits_of(c2), word[4 * e + 3], bits_of(c3)};
+      *reinterpret_cast<u32x4*>(obase + (size_t)(32 * T * e)) = lo4;
+      *reinterpret_cast<u32x4*>(obase + (size_t)(32 * T * e) + 16) = hi4;
+    }
+  } else if (live && out) {
     char* obase = reinterpret_cast<char*>(out);
     const uint32_t ooff = (frame * (uint32_t)N + 4u * (uint32_t)tau) * 4u;
 #pragma unroll
@@ -1096,7 +1191,7 @@ chain1d_gos_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint
   uint2* det_stage = reinterpret_cast<uint2*>(fbase + lay.det_off + 8);
   const bool wrap = rg.edge != 0;
   __syncthreads();  // every thread is done reading the FFT image this overlays
-  write_mag<M, V>(mag, kHalo, tau, mg);
+  write_mag<M, V>(mag, kHalo, tau, mg, rg.rev_order != 0);
   if (tau == 0) *det_cnt = 0u;
   __syncthreads();
   for (int h = tau; h < 32; h += T) {  // halos: 32 runs of 16 cells, zeros or the wrapped image
@@ -1137,7 +1232,8 @@ chain1d_gos_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint
       word[j] = CfarMath<V>::finish(stat, cut, group_ok, tau + T * j, M, rg);
     }
   }
-  emit_words<M>(word, out, frame, live, tau, det_cnt, det_stage, fcount, fdet);
+  emit_words<M, V>(word, out, frame, live, tau, det_cnt, det_stage, fcount, fdet,
+                   rg.send_cut ? mag + pad(tau + kHalo) : nullptr, T + T / 16);
 }
 
 // ---------------------------------------------------------------- launcher
@@ -1243,7 +1339,7 @@ hipError_t launch_chain1d(const Chain1dLaunch& a0) {
   for (uint32_t done = 0; done < a0.n_frames; done += max_frames) {
     a.n_frames = a0.n_frames - done < max_frames ? a0.n_frames - done : max_frames;
     a.in = static_cast<const char*>(a0.in) + ((uint64_t)done << a0.log2n) * beat;
-    a.out = a0.out ? a0.out + ((uint64_t)done << a0.log2n) : nullptr;
+    a.out = a0.out ? a0.out + (((uint64_t)done << a0.log2n) << (a0.regs.send_cut ? 1 : 0)) : nullptr;
     a.frame_count = a0.frame_count ? a0.frame_count + done : nullptr;
     a.frame_det = a0.frame_det ? a0.frame_det + (uint64_t)done * kFrameDetCap : nullptr;
     hipError_t e;
@@ -1299,7 +1395,7 @@ __device__ __forceinline__ uint32_t reserve_block(uint32_t* counters, uint32_t f
 // the list is reserved from the scanned per-frame counts).
 __global__ void __launch_bounds__(256)
 compact_frames_kernel(const uint32_t* __restrict__ fcount, const uint2* __restrict__ fdet,
-                      uint32_t n_frames, const uint32_t* __restrict__ words, int log2n,
+                      uint32_t n_frames, const uint32_t* __restrict__ words, int log2n, int word_shift,
                       rsp_detection* __restrict__ list, uint32_t cap,
                       uint32_t* __restrict__ counters, uint32_t* __restrict__ d_count) {
   __shared__ uint32_t wave_tot[4], wave_found[4];
@@ -1355,9 +1451,9 @@ compact_frames_kernel(const uint32_t* __restrict__ fcount, const uint2* __restri
     if (threadIdx.x == 0) ovf_cursor = 0u;
     __syncthreads();
     const uint32_t of = ovf_frame[q], ob = ovf_base[q];
-    const uint32_t* row = words + ((size_t)of << log2n);
+    const uint32_t* row = words + (((size_t)of << log2n) << word_shift);  // word_shift = 1: 64-bit beats {word, cut}
     for (uint32_t x = threadIdx.x; x < (1u << log2n); x += 256) {
-      const uint32_t w = row[x];
+      const uint32_t w = row[(size_t)x << word_shift];
       if (w & 1u) {
         const uint32_t slot = ob + atomicAdd(&ovf_cursor, 1u);
         if (slot < cap) {
@@ -1376,11 +1472,11 @@ compact_frames_kernel(const uint32_t* __restrict__ fcount, const uint2* __restri
 }
 
 hipError_t launch_compact_frames(const uint32_t* fcount, const uint2* fdet, uint32_t n_frames,
-                                 const uint32_t* words, int log2n, rsp_detection* list, uint32_t cap,
-                                 uint32_t* counters, uint32_t* d_count, hipStream_t stream) {
+                                 const uint32_t* words, int log2n, int word_shift, rsp_detection* list,
+                                 uint32_t cap, uint32_t* counters, uint32_t* d_count, hipStream_t stream) {
   if (n_frames == 0) return hipMemsetAsync(d_count, 0, 2 * sizeof(uint32_t), stream);
   hipLaunchKernelGGL(compact_frames_kernel, dim3((n_frames + 255) / 256), dim3(256), 0, stream,
-                     fcount, fdet, n_frames, words, log2n, list, cap, counters, d_count);
+                     fcount, fdet, n_frames, words, log2n, word_shift, list, cap, counters, d_count);
   return hipGetLastError();
 }
 
@@ -1393,8 +1489,10 @@ constexpr int kCompactCellsPerWg = 16384;
 
 __global__ void __launch_bounds__(256)
 compact_kernel(const uint32_t* __restrict__ words, uint64_t n_cells, uint32_t log2_row,
-               uint32_t log2_rows_per_frame, rsp_detection* __restrict__ list, uint32_t cap,
+               uint32_t log2_rows_per_frame, uint32_t word_shift, rsp_detection* __restrict__ list, uint32_t cap,
                uint32_t* __restrict__ counters, uint32_t* __restrict__ d_count) {
+  // word_shift = 1: 64-bit beats {word, cut} (sendCut): n_cells counts 32-bit WORDS, every other one is a cut
+  const uint32_t odd = word_shift ? 0u : 1u;
   __shared__ uint32_t wave_cnt[4];
   __shared__ uint32_t base_sh;
   const uint64_t lo = (uint64_t)blockIdx.x * kCompactCellsPerWg;
@@ -1408,7 +1506,7 @@ compact_kernel(const uint32_t* __restrict__ words, uint64_t n_cells, uint32_t lo
     w[j] = c < n_cells ? *reinterpret_cast<const u32x4*>(words + c) : u32x4{0u, 0u, 0u, 0u};
   }
 #pragma unroll
-  for (int j = 0; j < 16; ++j) mine += (w[j].x & 1u) + (w[j].y & 1u) + (w[j].z & 1u) + (w[j].w & 1u);
+  for (int j = 0; j < 16; ++j) mine += (w[j].x & 1u) + (w[j].y & odd) + (w[j].z & 1u) + (w[j].w & odd);
   uint32_t inc = mine;  // inclusive scan over the wave
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -1433,9 +1531,9 @@ compact_kernel(const uint32_t* __restrict__ words, uint64_t n_cells, uint32_t lo
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const uint32_t v = v4[q];
-        if (v & 1u) {
+        if ((v & 1u) && ((q & 1) == 0 || odd)) {
           if (slot < cap) {
-            const uint64_t i = c + q;
+            const uint64_t i = (c + q) >> word_shift;
             rsp_detection d;
             d.bin = (uint32_t)(i & ((1ull << log2_row) - 1ull));
             const uint64_t row = i >> log2_row;
@@ -1470,12 +1568,13 @@ hipError_t launch_compact_finalize(uint32_t* counters, uint32_t cap, uint32_t* d
 }
 
 hipError_t launch_compact(const uint32_t* words, uint64_t n_cells, uint32_t log2_row,
-                          uint32_t log2_rows_per_frame, rsp_detection* list, uint32_t cap,
+                          uint32_t log2_rows_per_frame, uint32_t word_shift, rsp_detection* list, uint32_t cap,
                           uint32_t* counters, uint32_t* d_count, hipStream_t stream) {
   if (n_cells == 0) return hipMemsetAsync(d_count, 0, 2 * sizeof(uint32_t), stream);
-  const uint64_t blocks = (n_cells + kCompactCellsPerWg - 1) / kCompactCellsPerWg;
-  hipLaunchKernelGGL(compact_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, words, n_cells,
-                     log2_row, log2_rows_per_frame, list, cap, counters, d_count);
+  const uint64_t n_words = n_cells << word_shift;
+  const uint64_t blocks = (n_words + kCompactCellsPerWg - 1) / kCompactCellsPerWg;
+  hipLaunchKernelGGL(compact_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, words, n_words,
+                     log2_row, log2_rows_per_frame, word_shift, list, cap, counters, d_count);
   hipLaunchKernelGGL(compact_finalize_kernel, dim3(1), dim3(1), 0, stream, counters, cap, d_count, false);
   return hipGetLastError();
 }

@@ -23,6 +23,13 @@ struct ChainRegs {
   // linear: thr = ((stat * scaler) << lin_shl) >> lin_shr   (one of the two is 0)
   // log:    thr = ((stat << log_shl) >> log_shr) + log_scaler
   int32_t lin_shl, lin_shr, log_shl, log_shr, log_scaler, tmax, tmin;
+  // elaboration options every reference configuration leaves at their defaults (all 0 here)
+  uint32_t keep_lsb_mask;  // bit s: FFTParams keepMSBorLSB(s) = false -- stage s drops its MSB instead of its LSB
+  uint32_t expand_mask;    // bit s: FFTParams expandLogic(s) = 1 -- stage s keeps its (w+1)-bit results
+  int32_t growth;          // popcount of expand_mask over the active stages: bits shed at the FFT output
+  int32_t rev_order;       // 1: FFTParams useBitReverse = false -- stream position p carries bin bitrev(p)
+  int32_t send_cut;        // 1: CFARParams sendCut = true -- 64-bit output beat {word, cut}
+  const void* window;      // pre-FFT window coefficients (float / Q1.15 int16 per sample), or NULL
 };
 
 constexpr int kMinLog2N = 8;       // LDS-tiled kernels: scan rows are 16 lanes x 16 cells = 256 cells

@@ -401,4 +401,56 @@ __device__ __forceinline__ void pass_fx(int (&xr)[16], int (&xi)[16], int tau, c
   }
 }
 
+// The same pass with the per-stage options of FFTParams.fixed that no reference configuration uses
+// (expandLogic(s) = 1: the stage keeps its (w+1)-bit results; keepMSBorLSB(s) = false: it drops the MSB
+// instead of the LSB) -- spec: docs/FIXED_POINT_SPEC.md section 3, oracle: orc_fft_fixed_ex.  Generic and
+// slow on purpose (64-bit products, run-time shifts); values stay below 2^29 and live in 32-bit registers.
+__device__ __forceinline__ long long trim_var(long long x, int n, const ChainRegs& rg) {
+  if (n <= 0) return x;
+  const long long half = rg.trim_bias1 ? (1ll << (n - 1)) : 0ll;  // trim_bias1 != 0 <=> not floor
+  const long long t = x + half;
+  long long r = t >> n;
+  if (rg.trim_conv && (t & ((1ll << n) - 1ll)) == 0) r &= ~1ll;
+  return r;
+}
+__device__ __forceinline__ int wrap_bits(long long x, int bits) {
+  return (int)((x << (64 - bits)) >> (64 - bits));
+}
+
+template <int M, int P>
+__device__ __forceinline__ void pass_fx_opt(int (&xr)[16], int (&xi)[16], int tau, const uint32_t* tw,
+                                            const ChainRegs& rg) {
+  constexpr int W = plan_w(M, P), LO = plan_lo(M, P), G = 16 >> W, T = threads_per_frame(M);
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int low = (g * T + tau) & ((1 << LO) - 1);
+#pragma unroll
+    for (int st = 0; st < W; ++st) {
+      const int bl = W - 1 - st;
+      const int s = M - 1 - (LO + bl);  // radix-2 stage number of this bit
+      const int grow = (int)((rg.expand_mask >> s) & 1u);
+      const int lsb = !grow && ((rg.keep_lsb_mask >> s) & 1u);
+      const int sh_sum = (grow || lsb) ? 0 : 1, sh_prod = 14 + sh_sum;
+      const int wout = 16 + __popc(rg.expand_mask & ((2u << s) - 1u));
+      const uint32_t* tws = tw + (low << s);
+#pragma unroll
+      for (int r0 = 0; r0 < (1 << W); ++r0) {
+        if (r0 & (1 << bl)) continue;
+        const int r1 = r0 | (1 << bl);
+        const int jj = r0 & ((1 << bl) - 1);
+        const uint32_t w = tws[(jj << LO) << s];
+        const long long wr = (short)(w >> 16), wi = (short)(w & 0xffffu);
+        const int ia = g * (1 << W) + r0, ib = g * (1 << W) + r1;
+        const long long sr = (long long)xr[ia] + xr[ib], si = (long long)xi[ia] + xi[ib];
+        const long long dr = (long long)xr[ia] - xr[ib], di = (long long)xi[ia] - xi[ib];
+        const long long pr = dr * wr - di * wi, pi = dr * wi + di * wr;
+        xr[ia] = wrap_bits(trim_var(sr, sh_sum, rg), wout);
+        xi[ia] = wrap_bits(trim_var(si, sh_sum, rg), wout);
+        xr[ib] = wrap_bits(trim_var(pr, sh_prod, rg), wout);
+        xi[ib] = wrap_bits(trim_var(pi, sh_prod, rg), wout);
+      }
+    }
+  }
+}
+
 }  // namespace rsp

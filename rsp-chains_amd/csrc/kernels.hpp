@@ -42,6 +42,7 @@ struct Rd2dLaunch {
   int ref_d, guard_d;   // Doppler training / guard half-widths
   const void* tw_range;
   const void* tw_doppler;
+  const void* win_doppler;  // slow-time window coefficients (float), or NULL; the fast-time one is regs.window
   void* scratch_complex;  // device: n_ch * nd * nr * 8 B
   float* scratch_mag;     // device: n_ch * nd * nr * 4 B
   hipStream_t stream;
@@ -65,13 +66,13 @@ constexpr int kCompactCounters = 3;
 // its dense words when `words` is given (complete list); without dense words it contributes its first
 // kFrameDetCap peaks and d_count[1] < d_count[0] tells.
 hipError_t launch_compact_frames(const uint32_t* fcount, const uint2* fdet, uint32_t n_frames,
-                                 const uint32_t* words, int log2n, rsp_detection* list, uint32_t cap,
-                                 uint32_t* counters, uint32_t* d_count, hipStream_t stream);
+                                 const uint32_t* words, int log2n, int word_shift, rsp_detection* list,
+                                 uint32_t cap, uint32_t* counters, uint32_t* d_count, hipStream_t stream);
 
 hipError_t launch_compact_finalize(uint32_t* counters, uint32_t cap, uint32_t* d_count, bool stored_is_found,
                                    hipStream_t stream);
 hipError_t launch_compact(const uint32_t* words, uint64_t n_cells, uint32_t log2_row,
-                          uint32_t log2_rows_per_frame, rsp_detection* list, uint32_t cap,
+                          uint32_t log2_rows_per_frame, uint32_t word_shift, rsp_detection* list, uint32_t cap,
                           uint32_t* counters, uint32_t* d_count, hipStream_t stream);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device), not per launch:

@@ -35,7 +35,7 @@ __device__ __forceinline__ float mag2d(f32x2 z, int mode) {
 template <int M>
 __global__ void __launch_bounds__(wg_size(M))
 range_fft_kernel(const f32x2* __restrict__ in, f32x2* __restrict__ out, uint32_t n_rows,
-                 const f32x2* __restrict__ tw) {
+                 const f32x2* __restrict__ tw, const float* __restrict__ win) {
   constexpr int N = 1 << M, T = threads_per_frame(M), FPW = frames_per_wg(M);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, fl = tid / T, tau = tid % T;
@@ -44,7 +44,12 @@ range_fft_kernel(const f32x2* __restrict__ in, f32x2* __restrict__ out, uint32_t
   f32x2* buf = reinterpret_cast<f32x2*>(smem) + (size_t)fl * fft_image_slots(M);
   const f32x2* src = in + (size_t)(live ? row : 0) * N + first_sample<M>(tau);
   f32x2 x[16];
-  fft_f32_frame<M>([&](int d) { return src[d]; }, tau, buf, tw, x);
+  if (win) {  // fast-time window (build extension)
+    const float* wsrc = win + first_sample<M>(tau);
+    fft_f32_frame<M>([&](int d) { const float wv = wsrc[d]; return src[d] * f32x2{wv, wv}; }, tau, buf, tw, x);
+  } else {
+    fft_f32_frame<M>([&](int d) { return src[d]; }, tau, buf, tw, x);
+  }
   // natural order through LDS, then 512 B per wave-instruction to HBM
   constexpr int NP = plan_np(M), WL = plan_w(M, NP - 1);
   const float scale = 1.0f / (float)N;
@@ -69,7 +74,7 @@ constexpr int kColBytes(int MD) { return 8 * fft_image_slots(MD) + 32; }
 template <int MD>
 __global__ void __launch_bounds__(threads_per_frame(MD) * kColsPerWg(MD))
 doppler_mag_kernel(const f32x2* __restrict__ in, float* __restrict__ mag, uint32_t n_ch, uint32_t nr,
-                   int mag_mode, const f32x2* __restrict__ tw) {
+                   int mag_mode, const f32x2* __restrict__ tw, const float* __restrict__ win) {
   constexpr int ND = 1 << MD, T = threads_per_frame(MD), C = kColsPerWg(MD);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // lanes run over the C adjacent range bins first: a wave touches 64 / C rows x (C x 8 B) segments
@@ -85,7 +90,12 @@ doppler_mag_kernel(const f32x2* __restrict__ in, float* __restrict__ mag, uint32
   const size_t col = (size_t)ch * ND * nr + r0 + fl;  // element index of (ch, d = 0, r)
   const f32x2* src = in + col + (size_t)first_sample<MD>(tau) * nr;
   f32x2 x[16];
-  fft_f32_frame<MD>([&](int d) { return src[(size_t)d * nr]; }, tau, buf, tw, x);
+  if (win) {  // slow-time window
+    const float* wsrc = win + first_sample<MD>(tau);
+    fft_f32_frame<MD>([&](int d) { const float wv = wsrc[d]; return src[(size_t)d * nr] * f32x2{wv, wv}; }, tau, buf, tw, x);
+  } else {
+    fft_f32_frame<MD>([&](int d) { return src[(size_t)d * nr]; }, tau, buf, tw, x);
+  }
   constexpr int NP = plan_np(MD), WL = plan_w(MD, NP - 1);
   const float scale = 1.0f / (float)ND;
   float* dst = mag + col;
@@ -377,7 +387,7 @@ cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, ui
 // ---------------------------------------------------------------- launchers
 
 template <int M>
-static hipError_t launch_range_m(const f32x2* in, f32x2* out, uint32_t n_rows, const f32x2* tw,
+static hipError_t launch_range_m(const f32x2* in, f32x2* out, uint32_t n_rows, const f32x2* tw, const float* win,
                                  hipStream_t s, int device) {
   const uint32_t fpw = frames_per_wg(M);
   const size_t lds = (size_t)8 * fft_image_slots(M) * fpw;
@@ -385,13 +395,13 @@ static hipError_t launch_range_m(const f32x2* in, f32x2* out, uint32_t n_rows, c
   static LdsGrant granted;
   hipError_t e = grant_lds(k, lds, device, granted);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k, dim3((n_rows + fpw - 1) / fpw), dim3(wg_size(M)), lds, s, in, out, n_rows, tw);
+  hipLaunchKernelGGL(k, dim3((n_rows + fpw - 1) / fpw), dim3(wg_size(M)), lds, s, in, out, n_rows, tw, win);
   return hipGetLastError();
 }
 
 template <int MD>
 static hipError_t launch_doppler_m(const f32x2* in, float* mag, uint32_t n_ch, uint32_t nr, int mode,
-                                   const f32x2* tw, hipStream_t s, int device) {
+                                   const f32x2* tw, const float* win, hipStream_t s, int device) {
   constexpr int C = kColsPerWg(MD);
   const size_t lds = (size_t)kColBytes(MD) * C;
   auto k = doppler_mag_kernel<MD>;
@@ -399,7 +409,7 @@ static hipError_t launch_doppler_m(const f32x2* in, float* mag, uint32_t n_ch, u
   hipError_t e = grant_lds(k, lds, device, granted);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3(n_ch * (nr / C)), dim3(threads_per_frame(MD) * C), lds, s, in, mag, n_ch,
-                     nr, mode, tw);
+                     nr, mode, tw, win);
   return hipGetLastError();
 }
 
@@ -411,21 +421,23 @@ hipError_t launch_rd2d(const Rd2dLaunch& a) {
   f32x2* x1 = reinterpret_cast<f32x2*>(a.scratch_complex);
   const f32x2* twr = reinterpret_cast<const f32x2*>(a.tw_range);
   const f32x2* twd = reinterpret_cast<const f32x2*>(a.tw_doppler);
+  const float* wr = reinterpret_cast<const float*>(a.regs.window);
+  const float* wd = reinterpret_cast<const float*>(a.win_doppler);
   const uint32_t rows = a.n_ch * nd;
   switch (a.log2nr) {
-    case 8: e = launch_range_m<8>(in, x1, rows, twr, a.stream, a.device); break;
-    case 9: e = launch_range_m<9>(in, x1, rows, twr, a.stream, a.device); break;
-    case 10: e = launch_range_m<10>(in, x1, rows, twr, a.stream, a.device); break;
-    case 11: e = launch_range_m<11>(in, x1, rows, twr, a.stream, a.device); break;
-    case 12: e = launch_range_m<12>(in, x1, rows, twr, a.stream, a.device); break;
-    case 13: e = launch_range_m<13>(in, x1, rows, twr, a.stream, a.device); break;
+    case 8: e = launch_range_m<8>(in, x1, rows, twr, wr, a.stream, a.device); break;
+    case 9: e = launch_range_m<9>(in, x1, rows, twr, wr, a.stream, a.device); break;
+    case 10: e = launch_range_m<10>(in, x1, rows, twr, wr, a.stream, a.device); break;
+    case 11: e = launch_range_m<11>(in, x1, rows, twr, wr, a.stream, a.device); break;
+    case 12: e = launch_range_m<12>(in, x1, rows, twr, wr, a.stream, a.device); break;
+    case 13: e = launch_range_m<13>(in, x1, rows, twr, wr, a.stream, a.device); break;
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
   switch (a.log2nd) {
-    case 8: e = launch_doppler_m<8>(x1, a.scratch_mag, a.n_ch, nr, a.regs.mag_mode, twd, a.stream, a.device); break;
-    case 9: e = launch_doppler_m<9>(x1, a.scratch_mag, a.n_ch, nr, a.regs.mag_mode, twd, a.stream, a.device); break;
-    case 10: e = launch_doppler_m<10>(x1, a.scratch_mag, a.n_ch, nr, a.regs.mag_mode, twd, a.stream, a.device); break;
+    case 8: e = launch_doppler_m<8>(x1, a.scratch_mag, a.n_ch, nr, a.regs.mag_mode, twd, wd, a.stream, a.device); break;
+    case 9: e = launch_doppler_m<9>(x1, a.scratch_mag, a.n_ch, nr, a.regs.mag_mode, twd, wd, a.stream, a.device); break;
+    case 10: e = launch_doppler_m<10>(x1, a.scratch_mag, a.n_ch, nr, a.regs.mag_mode, twd, wd, a.stream, a.device); break;
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;

@@ -68,6 +68,7 @@ struct rsp_chain {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::map<int, TwiddleRom> rom;  // keyed by log2n
+  std::map<int, void*> win;       // pre-FFT window tables, keyed by 64 * type + log2n
   int16_t* d_log_lut = nullptr;
   void* d_in = nullptr;
   size_t d_in_bytes = 0;
@@ -125,11 +126,14 @@ int validate(const rsp_chain_params* p) {
   if (f.dataWidth != 16 || f.twiddleWidth != 16)
     return fail(RSP_ERR_UNSUPPORTED, "dataWidth/twiddleWidth = %d/%d: only the reference's 16/16 is implemented",
                 f.dataWidth, f.twiddleWidth);
-  if (!f.useBitReverse) return fail(RSP_ERR_UNSUPPORTED, "useBitReverse = false (bit-reversed output order) is not implemented");
+  bool stage_opts = false;
   for (int s = 0; s < m_max; ++s) {
-    if (f.expandLogic[s] != 0 || f.keepMSBorLSB[s] != 1)
-      return fail(RSP_ERR_UNSUPPORTED, "stage %d: only expandLogic = 0 / keepMSBorLSB = true (FftMagCfarChain.scala:86-87) is implemented", s);
+    if ((f.expandLogic[s] != 0 && f.expandLogic[s] != 1) || (f.keepMSBorLSB[s] != 0 && f.keepMSBorLSB[s] != 1))
+      return fail(RSP_ERR_INVALID, "stage %d: expandLogic = %d / keepMSBorLSB = %d (0 or 1 each)", s, f.expandLogic[s], f.keepMSBorLSB[s]);
+    stage_opts |= f.expandLogic[s] != 0 || f.keepMSBorLSB[s] != 1;
   }
+  if (stage_opts && p->dtype != RSP_DTYPE_FIXED16)
+    return fail(RSP_ERR_INVALID, "expandLogic / keepMSBorLSB are properties of the FixedPoint data path (dtype = RSP_DTYPE_FIXED16)");
   if (f.trimType < RSP_TRIM_FLOOR || f.trimType > RSP_TRIM_CONVERGENT) return fail(RSP_ERR_INVALID, "trimType %d", f.trimType);
   if (f.binPoint < 0 || f.binPoint > 15 || m.binPoint != f.binPoint)
     return fail(RSP_ERR_INVALID, "binPoint fft/mag = %d/%d must agree and lie in 0..15", f.binPoint, m.binPoint);
@@ -142,7 +146,6 @@ int validate(const rsp_chain_params* p) {
     return fail(c.leadLaggWindowSize > rsp::kMaxRef ? RSP_ERR_UNSUPPORTED : RSP_ERR_INVALID,
                 "leadLaggWindowSize = %d (power of two <= %d)", c.leadLaggWindowSize, rsp::kMaxRef);
   if (c.guardWindowSize <= 0) return fail(RSP_ERR_INVALID, "guardWindowSize = %d", c.guardWindowSize);
-  if (c.sendCut) return fail(RSP_ERR_UNSUPPORTED, "sendCut = true widens the output beat beyond 32 bits; not implemented");
   if (c.CFARAlgorithm < RSP_ALG_CA || c.CFARAlgorithm > RSP_ALG_GOSCA) return fail(RSP_ERR_INVALID, "CFARAlgorithm %d", c.CFARAlgorithm);
   if (c.edgeMode != RSP_EDGE_ZERO && c.edgeMode != RSP_EDGE_WRAP) return fail(RSP_ERR_INVALID, "edgeMode %d", c.edgeMode);
   const rsp_fixed_proto* protos[3] = {&c.protoIn, &c.protoThreshold, &c.protoScaler};
@@ -167,7 +170,13 @@ int validate(const rsp_chain_params* p) {
       return fail(RSP_ERR_UNSUPPORTED, "dopplerPoints = %d: 256, 512 or 1024", p->dopplerPoints);
     if (p->refDoppler < 1 || p->guardDoppler < 0 || p->refDoppler + p->guardDoppler > 32)
       return fail(RSP_ERR_INVALID, "refDoppler/guardDoppler = %d/%d", p->refDoppler, p->guardDoppler);
+    if (c.sendCut || !f.useBitReverse)
+      return fail(RSP_ERR_UNSUPPORTED, "2-D chain (no reference counterpart): sendCut = true / useBitReverse = false are defined for the 1-D chain only");
   }
+  if (p->window < RSP_WINDOW_NONE || p->window > RSP_WINDOW_BLACKMAN || p->windowDoppler < RSP_WINDOW_NONE ||
+      p->windowDoppler > RSP_WINDOW_BLACKMAN)
+    return fail(RSP_ERR_INVALID, "window / windowDoppler = %d / %d", p->window, p->windowDoppler);
+  if (p->windowDoppler && !p->dopplerPoints) return fail(RSP_ERR_INVALID, "windowDoppler needs the 2-D chain (dopplerPoints > 0)");
   return RSP_OK;
 }
 
@@ -281,6 +290,18 @@ rsp::ChainRegs snapshot(const rsp_chain* c) {
   if (const char* m = getenv("RSP_ABLATE_MASK")) r.sub_window = atoi(m);
 #endif
   r.edge = p.cfarParams.edgeMode;
+  for (int s2 = 0; s2 < (int)c->fft_stages && s2 < RSP_MAX_STAGES; ++s2) {
+    // run-time FFT size: the active stages are the LAST log2(fftSize) stages of the elaborated pipeline
+    // (a smaller transform enters the SDF chain further down), so stage s of the active transform
+    // takes the options of elaborated stage s + (log2(numPoints) - stages)  [BUILD-DEFINED, spec section 3]
+    const int es = s2 + ilog2(p.fftParams.numPoints) - (int)c->fft_stages;
+    if (p.fftParams.expandLogic[es]) r.expand_mask |= 1u << s2;
+    else if (!p.fftParams.keepMSBorLSB[es]) r.keep_lsb_mask |= 1u << s2;
+  }
+  r.growth = __builtin_popcount(r.expand_mask);
+  r.rev_order = p.fftParams.useBitReverse ? 0 : 1;
+  r.send_cut = p.cfarParams.sendCut ? 1 : 0;
+  r.window = nullptr;
   {
     const int lin = r.bp_in + r.bp_scaler - r.bp_thr;  // oracle: trim_shift(stat * scaler, lin)
     r.lin_shr = lin > 0 ? lin : 0;
@@ -350,6 +371,43 @@ int get_rom(rsp_chain* c, int log2n, const void** out) {
   return RSP_OK;
 }
 
+// Pre-FFT window table (no reference item; spec section 2.1): n coefficients, symmetric form
+// w[i] = a0 - a1 cos(2 pi i / (n - 1)) + a2 cos(4 pi i / (n - 1)); fp32 for the F32 path, Q1.15 (x 32767,
+// round to nearest) for FIXED16.
+int get_window(rsp_chain* c, int type, int log2n, const void** out) {
+  *out = nullptr;
+  if (type == RSP_WINDOW_NONE) return RSP_OK;
+  const int key = 64 * type + log2n;
+  auto it = c->win.find(key);
+  if (it != c->win.end()) {
+    *out = it->second;
+    return RSP_OK;
+  }
+  const int n = 1 << log2n;
+  std::vector<double> w((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    const double x = 2.0 * M_PI * (double)i / (double)(n - 1);
+    w[i] = type == RSP_WINDOW_HANN ? 0.5 - 0.5 * std::cos(x)
+         : type == RSP_WINDOW_HAMMING ? 0.54 - 0.46 * std::cos(x)
+                                      : 0.42 - 0.5 * std::cos(x) + 0.08 * std::cos(2.0 * x);
+  }
+  void* d = nullptr;
+  if (c->p.dtype == RSP_DTYPE_F32) {
+    std::vector<float> h((size_t)n);
+    for (int i = 0; i < n; ++i) h[i] = (float)w[i];
+    HIP_TRY(hipMalloc(&d, h.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  } else {
+    std::vector<int16_t> h((size_t)n);
+    for (int i = 0; i < n; ++i) h[i] = (int16_t)std::lround(w[i] * 32767.0);
+    HIP_TRY(hipMalloc(&d, h.size() * sizeof(int16_t)));
+    HIP_TRY(hipMemcpy(d, h.data(), h.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+  }
+  c->win[key] = d;
+  *out = d;
+  return RSP_OK;
+}
+
 int ensure(void** ptr, size_t* have, size_t want) {
   if (*have >= want) return RSP_OK;
   if (*ptr) HIP_TRY(hipFree(*ptr));
@@ -393,6 +451,8 @@ int launch_dense(rsp_chain* c, const void* d_in, size_t n_frames, uint32_t* d_ou
   a.regs = snapshot(c);
   rc = get_rom(c, a.log2n, &a.twiddles);
   if (rc != RSP_OK) return rc;
+  rc = get_window(c, c->p.window, a.log2n, &a.regs.window);
+  if (rc != RSP_OK) return rc;
   a.log_lut = c->d_log_lut;
   a.stream = c->stream;
   a.device = c->device;
@@ -418,8 +478,8 @@ int launch_dense(rsp_chain* c, const void* d_in, size_t n_frames, uint32_t* d_ou
   HIP_TRY(rsp::launch_chain1d(a));
   if (pe1) HIP_TRY(hipEventRecord(pe1, c->stream));
   if (d_found)
-    HIP_TRY(rsp::launch_compact_frames(c->d_fcount, c->d_fdet, (uint32_t)n_frames, d_out, a.log2n, d_list, cap,
-                                       c->d_ctr, d_found, c->stream));
+    HIP_TRY(rsp::launch_compact_frames(c->d_fcount, c->d_fdet, (uint32_t)n_frames, d_out, a.log2n, a.regs.send_cut,
+                                       d_list, cap, c->d_ctr, d_found, c->stream));
   return RSP_OK;
 }
 
@@ -449,6 +509,10 @@ int launch_rd(rsp_chain* c, const void* d_in, size_t n_ch, uint32_t* d_out, rsp_
   rc = get_rom(c, a.log2nr, &a.tw_range);
   if (rc != RSP_OK) return rc;
   rc = get_rom(c, a.log2nd, &a.tw_doppler);
+  if (rc != RSP_OK) return rc;
+  rc = get_window(c, c->p.window, a.log2nr, &a.regs.window);
+  if (rc != RSP_OK) return rc;
+  rc = get_window(c, c->p.windowDoppler, a.log2nd, &a.win_doppler);
   if (rc != RSP_OK) return rc;
   a.scratch_complex = c->d_x1;
   a.scratch_mag = c->d_mag2;
@@ -583,6 +647,8 @@ void rsp_chain_destroy(rsp_chain* c) {
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
   for (auto& kv : c->rom)
     if (kv.second.d) (void)hipFree(kv.second.d);
+  for (auto& kv : c->win)
+    if (kv.second) (void)hipFree(kv.second);
   if (c->d_log_lut) (void)hipFree(c->d_log_lut);
   if (c->d_in) (void)hipFree(c->d_in);
   if (c->d_out) (void)hipFree(c->d_out);
@@ -673,7 +739,7 @@ int rsp_chain_process(rsp_chain* c, const void* in_beats, size_t n_frames, uint3
     return fail(RSP_ERR_INVALID, "n_frames = %zu too large for one call", n_frames);
   const size_t cells = (n_frames * (size_t)(c->p.dopplerPoints ? c->p.dopplerPoints : 1)) << c->fft_stages;
   if (c->p.dopplerPoints && cells > 0x7fffffffull) return fail(RSP_ERR_INVALID, "2-D chain: %zu channels too many for one call", n_frames);
-  const size_t in_bytes = cells * beat_bytes(c), out_bytes = cells * sizeof(uint32_t);
+  const size_t in_bytes = cells * beat_bytes(c), out_bytes = cells * sizeof(uint32_t) * (c->p.cfarParams.sendCut ? 2 : 1);
   rc = ensure(&c->d_in, &c->d_in_bytes, in_bytes);
   if (rc != RSP_OK) return rc;
   rc = ensure(reinterpret_cast<void**>(&c->d_out), &c->d_out_bytes, out_bytes);
@@ -696,7 +762,8 @@ int rsp_chain_detections_device(rsp_chain* c, const uint32_t* d_out_words, size_
   HIP_TRY(hipSetDevice(c->device));
   const uint32_t log2_rows = c->p.dopplerPoints ? (uint32_t)ilog2(c->p.dopplerPoints) : 0u;
   const uint64_t cells = ((uint64_t)n_frames << c->fft_stages) << log2_rows;
-  HIP_TRY(rsp::launch_compact(d_out_words, cells, c->fft_stages, log2_rows, d_list, cap, c->d_ctr, d_count, c->stream));
+  HIP_TRY(rsp::launch_compact(d_out_words, cells, c->fft_stages, log2_rows, c->p.cfarParams.sendCut ? 1u : 0u, d_list, cap,
+                              c->d_ctr, d_count, c->stream));
   return RSP_OK;
 }
 
@@ -718,7 +785,7 @@ int rsp_chain_process_detections(rsp_chain* c, const void* in_beats, size_t n_fr
   if (rc != RSP_OK) return rc;
   // dense words are kept on the device: a frame with more than RSP_FRAME_DET_CAP peaks is completed
   // from them, so the host call never truncates a frame
-  rc = ensure(reinterpret_cast<void**>(&c->d_out), &c->d_out_bytes, cells * sizeof(uint32_t));
+  rc = ensure(reinterpret_cast<void**>(&c->d_out), &c->d_out_bytes, cells * sizeof(uint32_t) * (c->p.cfarParams.sendCut ? 2 : 1));
   if (rc != RSP_OK) return rc;
   size_t list_bytes = c->d_list_cap * sizeof(rsp_detection);
   rc = ensure(reinterpret_cast<void**>(&c->d_list), &list_bytes, std::max<size_t>(cap, 1) * sizeof(rsp_detection));

@@ -11,6 +11,7 @@
 #include <type_traits>
 
 #include "chain_regs.hpp"
+#include "fft_lds.hpp"
 #include "kernels.hpp"
 
 namespace rsp {
@@ -98,15 +99,22 @@ chain1d_small_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, ui
     const uint32_t* src = reinterpret_cast<const uint32_t*>(in) + (size_t)(live ? frame : 0) * n;
     for (int i = 0; i < n; ++i) {
       const uint32_t b = src[i];  // {re[31:16], im[15:0]}: RspChainTesterUtils.scala:105-109
-      AT(xr, i) = (int)(short)(b >> 16);
-      AT(xi, i) = (int)(short)(b & 0xffffu);
+      int re = (int)(short)(b >> 16), im = (int)(short)(b & 0xffffu);
+      if (rg.window) {  // Q1.15 coefficient, product rounded half-up (spec section 2.1)
+        const int wq = reinterpret_cast<const int16_t*>(rg.window)[i];
+        re = (int)(short)((re * wq + (1 << 14)) >> 15);
+        im = (int)(short)((im * wq + (1 << 14)) >> 15);
+      }
+      AT(xr, i) = re;
+      AT(xi, i) = im;
     }
   } else {
     const float2* src = reinterpret_cast<const float2*>(in) + (size_t)(live ? frame : 0) * n;
     for (int i = 0; i < n; ++i) {
       const float2 z = src[i];
-      AT(xr, i) = z.x;
-      AT(xi, i) = z.y;
+      const float wv = rg.window ? reinterpret_cast<const float*>(rg.window)[i] : 1.0f;
+      AT(xr, i) = z.x * wv;
+      AT(xi, i) = z.y * wv;
     }
   }
   // ---- radix-2 DIF, stage by stage, in place (result bit-reversed)
@@ -120,10 +128,19 @@ chain1d_small_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, ui
           const int wr = (int)(short)(w >> 16), wi = (int)(short)(w & 0xffffu);
           const int ar = AT(xr, a), ai = AT(xi, a), br = AT(xr, b), bi = AT(xi, b);
           const int dr = ar - br, di = ai - bi;
-          AT(xr, a) = (int)(short)trim_s(ar + br, 1, rg.trim_bias1, rg.trim_conv);
-          AT(xi, a) = (int)(short)trim_s(ai + bi, 1, rg.trim_bias1, rg.trim_conv);
-          AT(xr, b) = (int)(short)trim_s(dr * wr - di * wi, 15, rg.trim_bias15, rg.trim_conv);
-          AT(xi, b) = (int)(short)trim_s(dr * wi + di * wr, 15, rg.trim_bias15, rg.trim_conv);
+          if (rg.keep_lsb_mask | rg.expand_mask) {  // per-stage options: spec section 3, as fft_lds.hpp pass_fx_opt
+            const int grow = (int)((rg.expand_mask >> s) & 1u), lsb = !grow && ((rg.keep_lsb_mask >> s) & 1u);
+            const int sh = (grow || lsb) ? 0 : 1, wout = 16 + __popc(rg.expand_mask & ((2u << s) - 1u));
+            AT(xr, a) = wrap_bits(trim_var((long long)ar + br, sh, rg), wout);
+            AT(xi, a) = wrap_bits(trim_var((long long)ai + bi, sh, rg), wout);
+            AT(xr, b) = wrap_bits(trim_var((long long)dr * wr - (long long)di * wi, 14 + sh, rg), wout);
+            AT(xi, b) = wrap_bits(trim_var((long long)dr * wi + (long long)di * wr, 14 + sh, rg), wout);
+          } else {
+            AT(xr, a) = (int)(short)trim_s(ar + br, 1, rg.trim_bias1, rg.trim_conv);
+            AT(xi, a) = (int)(short)trim_s(ai + bi, 1, rg.trim_bias1, rg.trim_conv);
+            AT(xr, b) = (int)(short)trim_s(dr * wr - di * wi, 15, rg.trim_bias15, rg.trim_conv);
+            AT(xi, b) = (int)(short)trim_s(dr * wi + di * wr, 15, rg.trim_bias15, rg.trim_conv);
+          }
         } else {
           const float2 w = reinterpret_cast<const float2*>(tw)[k];
           const float ar = AT(xr, a), ai = AT(xi, a), br = AT(xr, b), bi = AT(xi, b);
@@ -139,8 +156,9 @@ chain1d_small_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, ui
   // ---- magnitude in natural order
   const float scale = 1.0f / (float)n;  // F32: net 1/N (FIXED16 halves per stage)
   for (int k = 0; k < n; ++k) {
-    const int p = (int)(__brev((unsigned)k) >> (32 - log2n));
-    if constexpr (FIXED) AT(mg, k) = SmallMath<int>::mag(AT(xr, p), AT(xi, p), rg, log_lut);
+    // useBitReverse = false: position k of the stream carries the in-place element k = bin bitrev(k)
+    const int p = rg.rev_order ? k : (int)(__brev((unsigned)k) >> (32 - log2n));
+    if constexpr (FIXED) AT(mg, k) = SmallMath<int>::mag((int)(short)(AT(xr, p) >> rg.growth), (int)(short)(AT(xi, p) >> rg.growth), rg, log_lut);
     else AT(mg, k) = SmallMath<float>::mag(AT(xr, p) * scale, AT(xi, p) * scale, rg, log_lut);
   }
   // ---- CFAR, direct window sums
@@ -189,7 +207,14 @@ chain1d_small_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, ui
     bool ok = true;
     if (rg.peak_grouping) ok = cut > cell(k - 1) && cut > cell(k + 1);
     const uint32_t word = SmallMath<V>::finish(stat, cut, ok, k, log2n, rg);
-    if (live && out) out[(size_t)frame * n + k] = word;
+    if (live && out) {
+      if (rg.send_cut) {  // 64-bit beat {word, cut}
+        out[2 * ((size_t)frame * n + k)] = word;
+        out[2 * ((size_t)frame * n + k) + 1] = __builtin_bit_cast(uint32_t, cut);
+      } else {
+        out[(size_t)frame * n + k] = word;
+      }
+    }
     if (live && fcount && (word & 1u)) {
       if (found < (uint32_t)kFrameDetCap) fdet[(size_t)frame * kFrameDetCap + found] = make_uint2((uint32_t)k, word);
       ++found;

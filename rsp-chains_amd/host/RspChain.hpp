@@ -176,7 +176,7 @@ class FftMagCfarChainVanilla {
   std::vector<uint32_t> stream(const std::vector<uint32_t>& beats) {
     const size_t n = (size_t)1 << memReadWord(params_.fftAddress.base);
     require(beats.size() % n == 0, "beats must be whole frames");
-    std::vector<uint32_t> out(beats.size());
+    std::vector<uint32_t> out(beats.size() * (params_.cfarParams.c.sendCut ? 2 : 1));  // sendCut: {word, cut} per cell
     check(rsp_chain_process(h_, beats.data(), beats.size() / n, out.data()));
     return out;
   }

@@ -9,16 +9,36 @@ from oracle import oracle as O
 MODE_NAMES = {0: "Cell Averaging", 1: "Greatest Of", 2: "Smallest Of", 3: "CASH"}
 
 
+WINDOWS = {None: 0, "hann": 1, "hamming": 2, "blackman": 3}
+
+
 def make_params(n, dtype=R.FIXED16, bp=12, alg=R.CACFARType, edge="zero", trim="Convergent",
-                leadLagg=64, guard=4, proto=None, includeCASH=False):
+                leadLagg=64, guard=4, proto=None, includeCASH=False, sendCut=False, useBitReverse=True,
+                expandLogic=(), keepMSBorLSB=(), window=None):
     pin, pthr, psc = proto or (R.FixedPoint(16, bp),) * 3
     return R.FftMagCfarVanillaParameters(
-        fftParams=R.FFTParams.fixed(numPoints=n, binPoint=bp, trimType=trim),
+        fftParams=R.FFTParams.fixed(numPoints=n, binPoint=bp, trimType=trim, useBitReverse=useBitReverse,
+                                    expandLogic=list(expandLogic), keepMSBorLSB=list(keepMSBorLSB)),
         magParams=R.MAGParams.fixed(binPoint=bp),
         cfarParams=R.CFARParams(protoIn=pin, protoThreshold=pthr, protoScaler=psc, leadLaggWindowSize=leadLagg,
                                 guardWindowSize=guard, fftSize=n, CFARAlgorithm=alg, edgeMode=edge,
-                                includeCASH=includeCASH),
-        dtype=dtype)
+                                includeCASH=includeCASH, sendCut=sendCut),
+        dtype=dtype, window=window)
+
+
+def stage_masks(params, rt):
+    """(keep_lsb_mask, expand_mask) of the ACTIVE stages: a run-time size below numPoints uses the last
+    log2(fftSize) stages of the elaborated pipeline (docs/FIXED_POINT_SPEC.md section 3)."""
+    f = params.fftParams
+    m, m_max = R.log2Up(rt.fftSize), R.log2Up(f.numPoints)
+    keep = expand = 0
+    for s in range(m):
+        es = s + m_max - m
+        if f.expandLogic[es]:
+            expand |= 1 << s
+        elif not f.keepMSBorLSB[es]:
+            keep |= 1 << s
+    return keep, expand
 
 
 def oracle_cfg(params, rt):
@@ -35,7 +55,9 @@ def oracle_cfg(params, rt):
         algorithm=1 if gos else 0, cfar_mode={v: k for k, v in MODE_NAMES.items()}[rt.CFARMode],
         ref_window=rt.refWindowSize, guard_window=rt.guardWindowSize,
         index_lagg=rt.indexLagg or 0, index_lead=rt.indexLead or 0, sub_window=rt.subWindowSize or 0,
-        edge={"zero": 0, "wrap": 1}[c.edgeMode])
+        edge={"zero": 0, "wrap": 1}[c.edgeMode], keep_lsb_mask=stage_masks(params, rt)[0],
+        expand_mask=stage_masks(params, rt)[1], no_bit_reverse=0 if f.useBitReverse else 1,
+        send_cut=int(c.sendCut), window=WINDOWS[params.window])
 
 
 def oracle_fcfg(params, rt):
@@ -48,7 +70,8 @@ def oracle_fcfg(params, rt):
         peak_grouping=rt.peakGrouping, algorithm=1 if gos else 0,
         cfar_mode={v: k for k, v in MODE_NAMES.items()}[rt.CFARMode], ref_window=rt.refWindowSize,
         guard_window=rt.guardWindowSize, index_lagg=rt.indexLagg or 0, index_lead=rt.indexLead or 0,
-        edge={"zero": 0, "wrap": 1}[c.edgeMode], sub_window=rt.subWindowSize or 0)
+        edge={"zero": 0, "wrap": 1}[c.edgeMode], sub_window=rt.subWindowSize or 0,
+        no_bit_reverse=0 if params.fftParams.useBitReverse else 1, window=WINDOWS[params.window])
 
 
 def random_beats(n_frames, n, seed, amp=12000):

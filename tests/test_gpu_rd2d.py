@@ -10,11 +10,11 @@ from helpers import compare_f32
 pytestmark = pytest.mark.gpu
 
 
-def rd_params(nr, nd, ref=8, guard=2, edge="zero"):
+def rd_params(nr, nd, ref=8, guard=2, edge="zero", window=None, windowDoppler=None):
     return R.FftMagCfarVanillaParameters(
         fftParams=R.FFTParams.fixed(numPoints=nr), magParams=R.MAGParams.fixed(),
         cfarParams=R.CFARParams(fftSize=nr, leadLaggWindowSize=16, guardWindowSize=4, edgeMode=edge),
-        dtype=R.F32, dopplerPoints=nd, refDoppler=ref, guardDoppler=guard)
+        dtype=R.F32, dopplerPoints=nd, refDoppler=ref, guardDoppler=guard, window=window, windowDoppler=windowDoppler)
 
 
 def targets(n_ch, nd, nr, seed, k=4, sigma=0.05):
@@ -51,6 +51,25 @@ def test_rd2d_against_oracle(gpu, nr, nd, edge):
                 mag.reshape(n_ch, -1))
     for ch, db, rb in where:           # every injected target is detected at its (Doppler, range) cell
         assert words[ch, db, rb] & 1
+
+
+@pytest.mark.parametrize("wr,wd", [("hann", None), (None, "hamming"), ("blackman", "hann")])
+def test_rd2d_windows(gpu, wr, wd):
+    """Pre-FFT windows over fast time (range) and slow time (Doppler): SURVEY 8f-n4, no reference item."""
+    nr, nd, n_ch = 1024, 256, 2
+    params = rd_params(nr, nd, window=wr, windowDoppler=wd)
+    rt = R.RunTimeRspChainParams(fftSize=nr, CFARMode="Cell Averaging", refWindowSize=8, guardWindowSize=2, divSum=4,
+                                 thresholdScaler=4.0)
+    x, _ = targets(n_ch, nd, nr, seed=31)
+    with R.FftMagCfarChainVanilla(params) as dut:
+        dut.configure(rt)
+        words = dut.stream(x)
+    code = {None: 0, "hann": 1, "hamming": 2, "blackman": 3}
+    cfg = O.OrcRdCfg(log2nr=10, log2nd=8, mag_mode=O.MAG_JPL, scaler=4.0, ref_r=8, ref_d=8, guard_r=2, guard_d=2, edge=0,
+                     window_r=code[wr], window_d=code[wd])
+    thr, peak, margin, mag = O.rd_f32(x, cfg, want_mag=True)
+    compare_f32(words.reshape(n_ch, -1), thr.reshape(n_ch, -1), peak.reshape(n_ch, -1), margin.reshape(n_ch, -1),
+                mag.reshape(n_ch, -1))
 
 
 def test_rd2d_cfg5_shape_one_channel_against_oracle(gpu):

@@ -28,12 +28,14 @@ def test_reference_parameter_sets_validate():
     (lambda p: (setattr(p.fftParams, "numPoints", 8), setattr(p.cfarParams, "fftSize", 8)), N.RSP_ERR_UNSUPPORTED),
     (lambda p: setattr(p.fftParams, "numPoints", 16384), N.RSP_ERR_UNSUPPORTED),
     (lambda p: setattr(p.fftParams, "dataWidth", 18), N.RSP_ERR_UNSUPPORTED),
-    (lambda p: setattr(p.fftParams, "useBitReverse", False), N.RSP_ERR_UNSUPPORTED),
-    (lambda p: setattr(p.fftParams, "expandLogic", [1] * 10), N.RSP_ERR_UNSUPPORTED),
+    (lambda p: setattr(p.fftParams, "expandLogic", [2] * 10), N.RSP_ERR_INVALID),
+    (lambda p: (setattr(p.fftParams, "expandLogic", [1] * 10), setattr(p, "dtype", R.F32)), N.RSP_ERR_INVALID),
+    (lambda p: (setattr(p.fftParams, "useBitReverse", False), setattr(p, "dopplerPoints", 256), setattr(p, "refDoppler", 4),
+                setattr(p, "dtype", R.F32)), N.RSP_ERR_UNSUPPORTED),
+    (lambda p: setattr(p, "window", "kaiser"), None),
     (lambda p: setattr(p.cfarParams, "fftSize", 512), N.RSP_ERR_INVALID),
     (lambda p: setattr(p.cfarParams, "leadLaggWindowSize", 48), N.RSP_ERR_INVALID),
     (lambda p: setattr(p.cfarParams, "leadLaggWindowSize", 512), N.RSP_ERR_UNSUPPORTED),
-    (lambda p: setattr(p.cfarParams, "sendCut", True), N.RSP_ERR_UNSUPPORTED),
     (lambda p: setattr(p.cfarParams, "protoThreshold", R.FixedPoint(24, 12)), N.RSP_ERR_INVALID),
     (lambda p: setattr(p, "beatBytes", 8), N.RSP_ERR_UNSUPPORTED),
     (lambda p: setattr(p, "magAddress", R.AddressSet(0x30000100, 0xFF)), N.RSP_ERR_INVALID),
@@ -41,8 +43,20 @@ def test_reference_parameter_sets_validate():
 def test_invalid_parameters_are_rejected_with_a_reason(mutate, code):
     p = make_params(1024)
     mutate(p)
+    if code is None:   # rejected by the host mirror before it reaches the C ABI
+        with pytest.raises(ValueError, match="requirement failed"):
+            validate(p)
+        return
     rc, msg = validate(p)
     assert rc == code and len(msg) > 10
+
+
+def test_every_option_the_reference_types_accept_validates():
+    """FFTParams.fixed / CFARParams fields that round 1 rejected: sendCut, useBitReverse = false, per-stage
+    expandLogic / keepMSBorLSB (FftMagCfarChain.scala:82,86-87,107), + the window extension."""
+    for kw in (dict(sendCut=True), dict(useBitReverse=False), dict(expandLogic=[1, 0] * 5), dict(keepMSBorLSB=[False] * 10),
+               dict(window="hann"), dict(sendCut=True, useBitReverse=False, expandLogic=[0, 1] * 5, window="blackman")):
+        assert validate(make_params(1024, **kw))[0] == 0, kw
 
 
 def test_runtime_params_requires():
