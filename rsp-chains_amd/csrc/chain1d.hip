@@ -1081,63 +1081,89 @@ chain1d_quad_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uin
 
 template <typename V> __device__ __forceinline__ V vmin(V a, V b) { return a < b ? a : b; }
 template <typename V> __device__ __forceinline__ V vmax(V a, V b) { return a > b ? a : b; }
-template <> __device__ __forceinline__ float vmin<float>(float a, float b) { return fminf(a, b); }
-template <> __device__ __forceinline__ float vmax<float>(float a, float b) { return fmaxf(a, b); }
+// fminf / fmaxf quiet their operands first (a v_max x, x each); magnitudes are never NaN, and v_med3 with an
+// infinity is the same selection in ONE instruction (the infinities sit in SGPRs)
+template <> __device__ __forceinline__ float vmin<float>(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, -__builtin_inff()); }
+template <> __device__ __forceinline__ float vmax<float>(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
 // median of three, a <= c guaranteed by the caller
 template <typename V> __device__ __forceinline__ V vmed3(V a, V b, V c) { return vmin(vmax(a, b), c); }
 template <> __device__ __forceinline__ float vmed3<float>(float a, float b, float c) {
   return __builtin_amdgcn_fmed3f(a, b, c);
 }
 
+// The sorted window lives in ONE vector value (R consecutive VGPRs): every access below has a
+// compile-time index except the order-statistic pick, which the compiler then lowers to an indexed
+// register read (s_set_gpr_idx_on + v_mov: 3 instructions) -- the index-th register, wave-uniform.
+// With a plain C array the same pick became a scratch-memory copy (4x slower) or, blended by hand,
+// log2(R) levels of v_bfi (31 instructions per pick at R = 32).
+template <typename V, int R> struct WinVec { typedef V type __attribute__((ext_vector_type(R))); };
+
+// Batcher's odd-even merge sort, ascending: 191 compare-exchanges at R = 32 (bitonic: 240), 543 at R = 64 (672);
+// every index is a compile-time constant after unrolling
 template <typename V, int R>
-__device__ __forceinline__ void bitonic_sort(V (&s)[R]) {
+__device__ __forceinline__ void sort_window(typename WinVec<V, R>::type& s) {
 #pragma unroll
-  for (int k = 2; k <= R; k <<= 1) {
+  for (int p = 1; p < R; p <<= 1) {
 #pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
+    for (int k = p; k >= 1; k >>= 1) {
 #pragma unroll
-      for (int i = 0; i < R; ++i) {
-        const int l = i ^ j;
-        if (l > i) {
-          const V lo = vmin(s[i], s[l]), hi = vmax(s[i], s[l]);
-          const bool asc = (i & k) == 0;
-          s[i] = asc ? lo : hi;
-          s[l] = asc ? hi : lo;
+      for (int j = k % p; j <= R - 1 - k; j += 2 * k) {
+#pragma unroll
+        for (int i = 0; i <= (k - 1 < R - j - k - 1 ? k - 1 : R - j - k - 1); ++i) {
+          if ((i + j) / (2 * p) == (i + j + k) / (2 * p)) {
+            const V a = s[i + j], b = s[i + j + k];
+            s[i + j] = vmin(a, b);
+            s[i + j + k] = vmax(a, b);
+          }
         }
       }
     }
   }
 }
 
+// lane mask of a < b into an SGPR pair / select by such a mask.  Inline asm: the compiler pairs every compare
+// with its select through VCC (one register: compare i+1 cannot start before select i has read it) and pads
+// each pair with s_nop 1 for the VALU-writes-mask hazard; batches of 8 explicit masks need no padding.
+__device__ __forceinline__ unsigned long long cmp_lt_mask(float a, float b) {
+  unsigned long long m;
+  asm volatile("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+  return m;
+}
+__device__ __forceinline__ unsigned long long cmp_lt_mask(int a, int b) {
+  unsigned long long m;
+  asm volatile("v_cmp_lt_i32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+  return m;
+}
+template <typename V>
+__device__ __forceinline__ V select_mask(unsigned long long m, V if_set, V if_clear) {
+  V r;
+  asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+  return r;
+}
+
 // sorted s: remove one element equal to `old`, insert `nw`, stay sorted
 template <typename V, int R>
-__device__ __forceinline__ void slide(V (&s)[R], V old, V nw) {
+__device__ __forceinline__ void slide(typename WinVec<V, R>::type& s, V old, V nw) {
   V t[R - 1];
 #pragma unroll
-  for (int i = 0; i < R - 1; ++i) t[i] = s[i] < old ? s[i] : s[i + 1];
+  for (int b0 = 0; b0 < R - 1; b0 += 8) {
+    unsigned long long m[8];
+#pragma unroll
+    for (int i = b0; i < b0 + 8 && i < R - 1; ++i) {
+      const V a = s[i];
+      m[i - b0] = cmp_lt_mask(a, old);
+    }
+    if (R - 1 - b0 < 3) asm volatile("s_nop 1");  // a short last batch: keep 2 wait states between mask and select
+#pragma unroll
+    for (int i = b0; i < b0 + 8 && i < R - 1; ++i) {
+      const V a = s[i], b = s[i + 1];
+      t[i] = select_mask<V>(m[i - b0], a, b);
+    }
+  }
   s[0] = vmin(t[0], nw);
 #pragma unroll
   for (int i = 1; i < R - 1; ++i) s[i] = vmed3(t[i - 1], nw, t[i]);
   s[R - 1] = vmax(t[R - 2], nw);
-}
-
-// s[idx] for a wave-uniform idx: log2(R) levels of bitwise blends (v_bfi_b32) on the bits of idx.
-// Written on the bit patterns on purpose: a `cond ? a[2i+1] : a[2i]` with a uniform cond is
-// turned by the compiler into an indexed load from a scratch copy of the array (10x slower).
-template <typename V, int R>
-__device__ __forceinline__ V pick(const V (&s)[R], int idx) {
-  uint32_t a[R];
-#pragma unroll
-  for (int i = 0; i < R; ++i) a[i] = __builtin_bit_cast(uint32_t, s[i]);
-#pragma unroll
-  for (int w = R; w > 1; w >>= 1) {
-    uint32_t m = (idx & 1) ? 0xffffffffu : 0u;
-    asm volatile("" : "+s"(m));  // keep it a value, not a branch / address select
-    idx >>= 1;
-#pragma unroll
-    for (int i = 0; i < w / 2; ++i) a[i] = (a[2 * i + 1] & m) | (a[2 * i] & ~m);
-  }
-  return __builtin_bit_cast(V, a[0]);
 }
 
 struct GosLayout {  // byte offsets inside a frame's LDS, computed on the host
@@ -1148,15 +1174,15 @@ template <typename V, int R>
 __device__ __forceinline__ void gos_stage(const V* mag, V* o1, V* o2, int tau, int run, int G,
                                           int idx_lagg, int idx_lead) {
   const int a0 = -(G + R) + run * tau;  // first window start of this thread
-  V s[R];
+  typename WinVec<V, R>::type s;
 #pragma unroll
   for (int i = 0; i < R; ++i) s[i] = mag[pad(a0 + i + kHalo)];
-  bitonic_sort<V, R>(s);
+  sort_window<V, R>(s);
   const bool two = idx_lagg != idx_lead;
   for (int st = 0; st < run; ++st) {
     const int oi = pad(run * tau + st);
-    o1[oi] = pick<V, R>(s, idx_lagg);
-    if (two) o2[oi] = pick<V, R>(s, idx_lead);
+    o1[oi] = s[idx_lagg];
+    if (two) o2[oi] = s[idx_lead];
     if (st + 1 < run) {
       const V old = mag[pad(a0 + st + kHalo)], nw = mag[pad(a0 + st + R + kHalo)];
       slide<V, R>(s, old, nw);

@@ -245,8 +245,6 @@ int check_regs(const rsp_chain* c) {
   if (c->cfar[kAlgorithm] > 1) return fail(RSP_ERR_INVALID, "cfarAlgorithm register = %u", c->cfar[kAlgorithm]);
   if (uses_gos(c)) {
     if (m >= rsp::kMinLog2N && (R < 4 || R > 64)) return fail(RSP_ERR_UNSUPPORTED, "GOS CFAR: refWindowSize = %d, the GPU sorter is built for 4..64", R);
-    if (m == rsp::kMaxLog2N && c->cfar[kIndexLagg] != c->cfar[kIndexLead])
-      return fail(RSP_ERR_UNSUPPORTED, "GOS CFAR at %d points needs indexLagg == indexLead (LDS)", n);
   }
   if (p.dopplerPoints) {
     if (m != m_max) return fail(RSP_ERR_UNSUPPORTED, "2-D chain: run-time FFT size must equal numPoints");

@@ -27,8 +27,6 @@ def random_case(rng, dtype):
     mag = int(rng.choice([0, 1, 2, 2, 2]))
     linear = 0 if (mag == 1 and rng.random() < 0.7) else 1
     idx = (int(rng.integers(0, ref)), int(rng.integers(0, ref)))
-    if gos and n == 8192:
-        idx = (idx[0], idx[0])
     params = make_params(n if rng.random() < 0.5 else max(n, 1024), dtype=dtype, bp=bp, alg=alg,
                          edge=str(rng.choice(["zero", "wrap"])), trim=str(rng.choice(["RoundDown", "RoundHalfUp", "Convergent"])),
                          leadLagg=64, guard=8, includeCASH=cash)
