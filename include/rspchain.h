@@ -213,7 +213,8 @@ int rsp_chain_process_detections(rsp_chain* c, const void* in_beats, size_t n_fr
 enum {
   RSP_OPT_MAX_FRAMES_PER_LAUNCH = 1, /* split a call into launches of at most this many frames (0 = automatic) */
   RSP_OPT_FORCE_TILED_CFAR2D = 2,    /* 2-D chain: run-time-window CFAR kernel even for the compile-time windows */
-  RSP_OPT_FORCE_GENERIC_TAIL = 3     /* 1-D chain: per-cell CFAR tail even where the 16-byte "quad" tail applies */
+  RSP_OPT_FORCE_GENERIC_TAIL = 3,    /* 1-D chain: per-cell CFAR tail even where the 16-byte "quad" tail applies */
+  RSP_OPT_RD_CHUNK_BYTES = 4         /* 2-D chain: bytes of intermediates (12 B/cell) per chunk of channels; 0 = whole batch (default: chunks of 48-192 MiB measured 0-60 % slower) */
 };
 int rsp_chain_set_option(rsp_chain* c, int option, int64_t value);
 

@@ -378,7 +378,7 @@ class FftMagCfarChainVanilla:
         _check(self._lib.rsp_chain_detections_device(self._h, C.c_void_p(d_words), n_frames,
                                                      C.c_void_p(d_list), cap, C.c_void_p(d_count)))
 
-    MAX_FRAMES_PER_LAUNCH, FORCE_TILED_CFAR2D, FORCE_GENERIC_TAIL = 1, 2, 3   # RSP_OPT_* of include/rspchain.h
+    MAX_FRAMES_PER_LAUNCH, FORCE_TILED_CFAR2D, FORCE_GENERIC_TAIL, RD_CHUNK_BYTES = 1, 2, 3, 4   # RSP_OPT_* of include/rspchain.h
 
     def set_option(self, option: int, value: int):
         _check(self._lib.rsp_chain_set_option(self._h, option, value))

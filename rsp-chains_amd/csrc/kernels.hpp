@@ -48,6 +48,7 @@ struct Rd2dLaunch {
   hipStream_t stream;
   int device;
   bool force_tiled_cfar;  // tests: take the run-time-window kernel even for the compile-time windows
+  size_t chunk_bytes;     // intermediates (12 B/cell) per chunk of channels; 0 = the whole batch at once
   // optional fused detection list: the CFAR kernel appends its peak cells itself (one device-scope
   // atomic per PEAK, none otherwise), so no second pass over the dense words is needed
   rsp_detection* det_list;  // device, or NULL
@@ -56,6 +57,14 @@ struct Rd2dLaunch {
   uint32_t* det_count;      // device uint32[2]: {found, stored}, written by the finalize launch
 };
 hipError_t launch_rd2d(const Rd2dLaunch& a);
+// channels per chunk (>= 1) and the scratch the API has to provide for it
+inline uint32_t rd2d_chunk_channels(int log2nr, int log2nd, uint32_t n_ch, size_t chunk_bytes) {
+  if (chunk_bytes == 0) return n_ch;
+  const size_t per_ch = (size_t)12 << (log2nr + log2nd);
+  size_t k = chunk_bytes / per_ch;
+  if (k < 1) k = 1;
+  return k > n_ch ? n_ch : (uint32_t)k;
+}
 
 // Detection compaction.  `counters` = 3 device words owned by the chain handle {found, cursor, ticket},
 // zero between launches: the last workgroup to finish publishes d_count[0] = peaks found,

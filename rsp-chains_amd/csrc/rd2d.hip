@@ -50,24 +50,24 @@ range_fft_kernel(const f32x2* __restrict__ in, f32x2* __restrict__ out, uint32_t
   } else {
     fft_f32_frame<M>([&](int d) { return src[d]; }, tau, buf, tw, x);
   }
-  // natural order through LDS, then 512 B per wave-instruction to HBM
+  // register (g, p) holds bin (bitrev(p) << (M - WL)) | (g T + tau) (fft_lds.hpp, last pass): consecutive lanes hold
+  // consecutive bins, so the spectrum goes straight to HBM in natural order, 512 B per wave-instruction
   constexpr int NP = plan_np(M), WL = plan_w(M, NP - 1);
   const float scale = 1.0f / (float)N;
-  __syncthreads();
+  if (!live) return;
+  f32x2* dst = out + (size_t)row * N + tau;
 #pragma unroll
   for (int g = 0; g < (16 >> WL); ++g) {
 #pragma unroll
-    for (int p = 0; p < (1 << WL); ++p) buf[pad(bin_of<M>(tau, g, p))] = x[g * (1 << WL) + p] * scale;
+    for (int p = 0; p < (1 << WL); ++p) dst[(bitrev_c(p, WL) << (M - WL)) + g * T] = x[g * (1 << WL) + p] * scale;
   }
-  __syncthreads();
-  if (!live) return;
-  f32x2* dst = out + (size_t)row * N;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) dst[tau + T * j] = buf[pad(tau + T * j)];
 }
 
 // ---------------------------------------------------------------- Doppler pass (columns) + magnitude
-constexpr int kColsPerWg(int MD) { return MD >= 10 ? 8 : 16; }
+#ifndef RSP_DOPPLER_COLS10
+#define RSP_DOPPLER_COLS10 8
+#endif
+constexpr int kColsPerWg(int MD) { return MD >= 10 ? (RSP_DOPPLER_COLS10) : 16; }
 // LDS bytes per column: the padded FFT image + 32 B so that adjacent columns start 8 banks apart
 constexpr int kColBytes(int MD) { return 8 * fft_image_slots(MD) + 32; }
 
@@ -135,7 +135,7 @@ template <int SRR, int SGR, int SRD, int SGD>
 __global__ void __launch_bounds__(256)
 cfar2d_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_t nd, uint32_t nr,
               int ref_r_rt, int guard_r_rt, int ref_d_rt, int guard_d_rt, int edge, float kA, float kB,
-              rsp_detection* __restrict__ det_list, uint32_t det_cap, uint32_t* __restrict__ det_counters) {
+              rsp_detection* __restrict__ det_list, uint32_t det_cap, uint32_t* __restrict__ det_counters, uint32_t ch_base) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int ref_r = SRR >= 0 ? SRR : ref_r_rt, guard_r = SGR >= 0 ? SGR : guard_r_rt;
   const int ref_d = SRD >= 0 ? SRD : ref_d_rt, guard_d = SGD >= 0 ? SGD : guard_d_rt;
@@ -224,7 +224,7 @@ cfar2d_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_
       const float cut = m[(dseg + j + hd) * MS + c + hr];
       const uint32_t wd = (__float_as_uint(thr) & ~1u) | (uint32_t)(cut > thr);
       dst[(size_t)j * nr] = wd;
-      if (det_list && (wd & 1u)) append_peak(det_list, det_cap, det_counters, ch, (uint32_t)(d0 + dseg + j), (uint32_t)(r0 + c), wd);
+      if (det_list && (wd & 1u)) append_peak(det_list, det_cap, det_counters, ch_base + ch, (uint32_t)(d0 + dseg + j), (uint32_t)(r0 + c), wd);
       so += co[(j + hd + 1) * (kTR + 1)] - co[(j - hd) * (kTR + 1)];
       si += ci[(j + guard_d + 1) * (kTR + 1)] - ci[(j - guard_d) * (kTR + 1)];
     }
@@ -274,7 +274,7 @@ template <int RR, int GR, int RD, int GD, int SEG>
 __global__ void __launch_bounds__(256)
 cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_t nd, uint32_t nr,
                    uint32_t strips, int edge, float kA, float kB,
-                   rsp_detection* __restrict__ det_list, uint32_t det_cap, uint32_t* __restrict__ det_counters) {
+                   rsp_detection* __restrict__ det_list, uint32_t det_cap, uint32_t* __restrict__ det_counters, uint32_t ch_base) {
   constexpr int HR = RR + GR, HD = RD + GD, SPAN = 2 * HD + 2, RING = kWalkRing;
   constexpr int LB = walk_lb(HR), LE = walk_le(HR), OUTW = walk_outw(HR);
   static_assert(SPAN < RING && SEG % RING == 0, "ring holds the taps plus at least one row in flight");
@@ -340,11 +340,11 @@ cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, ui
       if ((wd.x | wd.y) & det_mask) {  // rare
         if (wd.x & 1u) {
           const uint32_t sl = atomicAdd(&stage_cnt[w], 1u);
-          if (sl < (uint32_t)kWalkStage) stage[w][sl] = u32x4{ch, (uint32_t)col, (uint32_t)(d0 + i), wd.x};
+          if (sl < (uint32_t)kWalkStage) stage[w][sl] = u32x4{ch_base + ch, (uint32_t)col, (uint32_t)(d0 + i), wd.x};
         }
         if (wd.y & 1u) {
           const uint32_t sl = atomicAdd(&stage_cnt[w], 1u);
-          if (sl < (uint32_t)kWalkStage) stage[w][sl] = u32x4{ch, (uint32_t)col + 1u, (uint32_t)(d0 + i), wd.y};
+          if (sl < (uint32_t)kWalkStage) stage[w][sl] = u32x4{ch_base + ch, (uint32_t)col + 1u, (uint32_t)(d0 + i), wd.y};
         }
       }
       vo += ring[(u + SPAN - 1) % RING] - ring[u];
@@ -377,8 +377,8 @@ cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, ui
 #pragma unroll 1
       for (int i = 0; i < SEG; ++i) {
         const u32x2 wd = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_out, voff_out, (uint32_t)(d0 + i) * nr * 4u, 1 /* glc */));
-        if (wd.x & 1u) append_peak(det_list, det_cap, det_counters, ch, (uint32_t)(d0 + i), (uint32_t)col, wd.x);
-        if (wd.y & 1u) append_peak(det_list, det_cap, det_counters, ch, (uint32_t)(d0 + i), (uint32_t)col + 1u, wd.y);
+        if (wd.x & 1u) append_peak(det_list, det_cap, det_counters, ch_base + ch, (uint32_t)(d0 + i), (uint32_t)col, wd.x);
+        if (wd.y & 1u) append_peak(det_list, det_cap, det_counters, ch_base + ch, (uint32_t)(d0 + i), (uint32_t)col + 1u, wd.y);
       }
     }
   }
@@ -413,17 +413,19 @@ static hipError_t launch_doppler_m(const f32x2* in, float* mag, uint32_t n_ch, u
   return hipGetLastError();
 }
 
-hipError_t launch_rd2d(const Rd2dLaunch& a) {
-  if (a.n_ch == 0) return hipSuccess;
+// one chunk of channels through the three kernels; scratch buffers are the chunk's own
+static hipError_t launch_rd2d_chunk(const Rd2dLaunch& a, uint32_t ch0, uint32_t n_ch) {
   const uint32_t nr = 1u << a.log2nr, nd = 1u << a.log2nd;
+  const size_t map = (size_t)nr * nd;
   hipError_t e;
-  const f32x2* in = reinterpret_cast<const f32x2*>(a.in);
+  const f32x2* in = reinterpret_cast<const f32x2*>(a.in) + (size_t)ch0 * map;
+  uint32_t* out = a.out + (size_t)ch0 * map;
   f32x2* x1 = reinterpret_cast<f32x2*>(a.scratch_complex);
   const f32x2* twr = reinterpret_cast<const f32x2*>(a.tw_range);
   const f32x2* twd = reinterpret_cast<const f32x2*>(a.tw_doppler);
   const float* wr = reinterpret_cast<const float*>(a.regs.window);
   const float* wd = reinterpret_cast<const float*>(a.win_doppler);
-  const uint32_t rows = a.n_ch * nd;
+  const uint32_t rows = n_ch * nd;
   switch (a.log2nr) {
     case 8: e = launch_range_m<8>(in, x1, rows, twr, wr, a.stream, a.device); break;
     case 9: e = launch_range_m<9>(in, x1, rows, twr, wr, a.stream, a.device); break;
@@ -435,9 +437,9 @@ hipError_t launch_rd2d(const Rd2dLaunch& a) {
   }
   if (e != hipSuccess) return e;
   switch (a.log2nd) {
-    case 8: e = launch_doppler_m<8>(x1, a.scratch_mag, a.n_ch, nr, a.regs.mag_mode, twd, wd, a.stream, a.device); break;
-    case 9: e = launch_doppler_m<9>(x1, a.scratch_mag, a.n_ch, nr, a.regs.mag_mode, twd, wd, a.stream, a.device); break;
-    case 10: e = launch_doppler_m<10>(x1, a.scratch_mag, a.n_ch, nr, a.regs.mag_mode, twd, wd, a.stream, a.device); break;
+    case 8: e = launch_doppler_m<8>(x1, a.scratch_mag, n_ch, nr, a.regs.mag_mode, twd, wd, a.stream, a.device); break;
+    case 9: e = launch_doppler_m<9>(x1, a.scratch_mag, n_ch, nr, a.regs.mag_mode, twd, wd, a.stream, a.device); break;
+    case 10: e = launch_doppler_m<10>(x1, a.scratch_mag, n_ch, nr, a.regs.mag_mode, twd, wd, a.stream, a.device); break;
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
@@ -451,23 +453,33 @@ hipError_t launch_rd2d(const Rd2dLaunch& a) {
     const uint32_t strips = (nr + walk_outw(10) - 1) / walk_outw(10);
     // 64 rows per wave: 32 measures the same, 128 is 6 % slower (fewer waves to hide the row latency)
     constexpr uint32_t SEG = 64;
-    hipLaunchKernelGGL((cfar2d_walk_kernel<8, 2, 8, 2, SEG>), dim3(a.n_ch * strips * (nd / SEG / 4)), dim3(256), 0,
-                       a.stream, a.scratch_mag, a.out, nd, nr, strips, a.regs.edge, kA, kB, a.det_list, a.det_cap,
-                       a.det_counters);
-    e = hipGetLastError();
-    if (e == hipSuccess && a.det_list) e = launch_compact_finalize(a.det_counters, a.det_cap, a.det_count, true, a.stream);
-    return e;
+    hipLaunchKernelGGL((cfar2d_walk_kernel<8, 2, 8, 2, SEG>), dim3(n_ch * strips * (nd / SEG / 4)), dim3(256), 0,
+                       a.stream, a.scratch_mag, out, nd, nr, strips, a.regs.edge, kA, kB, a.det_list, a.det_cap,
+                       a.det_counters, ch0);
+    return hipGetLastError();
   }
   auto k = cfar2d_kernel<-1, -1, -1, -1>;
   static LdsGrant granted;
   e = grant_lds(k, lds, a.device, granted);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k, dim3(a.n_ch * (nr / kTR) * (nd / kTD)), dim3(256), lds, a.stream, a.scratch_mag, a.out,
+  hipLaunchKernelGGL(k, dim3(n_ch * (nr / kTR) * (nd / kTD)), dim3(256), lds, a.stream, a.scratch_mag, out,
                      nd, nr, a.regs.R, a.regs.G, a.ref_d, a.guard_d, a.regs.edge, kA, kB, a.det_list, a.det_cap,
-                     a.det_counters);
-  e = hipGetLastError();
-  if (e == hipSuccess && a.det_list) e = launch_compact_finalize(a.det_counters, a.det_cap, a.det_count, true, a.stream);
-  return e;
+                     a.det_counters, ch0);
+  return hipGetLastError();
+}
+
+// Channels are independent: the batch runs in chunks whose intermediates (range spectrum 8 B/cell + magnitude map
+// 4 B/cell) fit the 256 MiB Infinity Cache together with the streams passing by, and every chunk reuses the SAME
+// scratch memory, so the corner turn and the magnitude map are re-read from cache instead of HBM.
+hipError_t launch_rd2d(const Rd2dLaunch& a) {
+  if (a.n_ch == 0) return hipSuccess;
+  const uint32_t per = rd2d_chunk_channels(a.log2nr, a.log2nd, a.n_ch, a.chunk_bytes);
+  for (uint32_t c0 = 0; c0 < a.n_ch; c0 += per) {
+    hipError_t e = launch_rd2d_chunk(a, c0, a.n_ch - c0 < per ? a.n_ch - c0 : per);
+    if (e != hipSuccess) return e;
+  }
+  if (a.det_list) return launch_compact_finalize(a.det_counters, a.det_cap, a.det_count, true, a.stream);
+  return hipSuccess;
 }
 
 }  // namespace rsp

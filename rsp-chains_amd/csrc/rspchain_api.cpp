@@ -93,6 +93,7 @@ struct rsp_chain {
   uint32_t opt_max_frames = 0;
   bool opt_force_tiled = false;
   bool opt_generic_tail = false;
+  size_t opt_rd_chunk_bytes = 0;  // 2-D chain: intermediates per chunk of channels (0 = whole batch: chunking measured slower)
 };
 
 namespace {
@@ -491,9 +492,12 @@ int launch_rd(rsp_chain* c, const void* d_in, size_t n_ch, uint32_t* d_out, rsp_
   HIP_TRY(hipSetDevice(c->device));
   const size_t cells = (n_ch * (size_t)c->p.dopplerPoints) << c->fft_stages;
   if (n_ch > 0xffffu || cells > 0x7fffffffull) return fail(RSP_ERR_INVALID, "2-D chain: %zu channels too many for one call", n_ch);
-  int rc = ensure(&c->d_x1, &c->d_x1_bytes, cells * 8);
+  // scratch for ONE chunk of channels (launch_rd2d): reused by every chunk, so it stays in the Infinity Cache
+  const size_t chunk_ch = rsp::rd2d_chunk_channels((int)c->fft_stages, ilog2(c->p.dopplerPoints), (uint32_t)n_ch, c->opt_rd_chunk_bytes);
+  const size_t chunk_cells = (chunk_ch * (size_t)c->p.dopplerPoints) << c->fft_stages;
+  int rc = ensure(&c->d_x1, &c->d_x1_bytes, chunk_cells * 8);
   if (rc != RSP_OK) return rc;
-  rc = ensure(reinterpret_cast<void**>(&c->d_mag2), &c->d_mag2_bytes, cells * 4);
+  rc = ensure(reinterpret_cast<void**>(&c->d_mag2), &c->d_mag2_bytes, chunk_cells * 4);
   if (rc != RSP_OK) return rc;
   rsp::Rd2dLaunch a{};
   a.in = d_in;
@@ -517,6 +521,7 @@ int launch_rd(rsp_chain* c, const void* d_in, size_t n_ch, uint32_t* d_out, rsp_
   a.stream = c->stream;
   a.device = c->device;
   a.force_tiled_cfar = c->opt_force_tiled;
+  a.chunk_bytes = c->opt_rd_chunk_bytes;
   if (d_found) {
     a.det_list = d_list;
     a.det_cap = cap;
@@ -818,6 +823,10 @@ int rsp_chain_set_option(rsp_chain* c, int option, int64_t value) {
       return RSP_OK;
     case RSP_OPT_FORCE_GENERIC_TAIL:
       c->opt_generic_tail = value != 0;
+      return RSP_OK;
+    case RSP_OPT_RD_CHUNK_BYTES:
+      if (value < 0) return fail(RSP_ERR_INVALID, "chunk bytes = %lld", (long long)value);
+      c->opt_rd_chunk_bytes = (size_t)value;
       return RSP_OK;
     default:
       return fail(RSP_ERR_INVALID, "unknown option %d", option);

@@ -13,6 +13,7 @@ params = R.FftMagCfarVanillaParameters(
     cfarParams=R.CFARParams(fftSize=nr, leadLaggWindowSize=16), dtype=R.F32, dopplerPoints=nd, refDoppler=8, guardDoppler=2)
 rt = R.RunTimeRspChainParams(fftSize=nr, CFARMode="Cell Averaging", refWindowSize=8, guardWindowSize=2, divSum=4, thresholdScaler=4.0)
 dut = R.FftMagCfarChainVanilla(params); dut.configure(rt)
+if os.environ.get("RSP_RD_CHUNK_MB") is not None: dut.set_option(dut.RD_CHUNK_BYTES, int(os.environ["RSP_RD_CHUNK_MB"]) << 20)
 rng = np.random.default_rng(2345)
 x = (0.05 * (rng.standard_normal((nd, nr)) + 1j * rng.standard_normal((nd, nr)))).astype(np.complex64)
 x = np.tile(x, (n_ch, 1, 1))
