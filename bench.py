@@ -257,6 +257,10 @@ def run_extra(w, torch, steps, warmup):
 # ---------------------------------------------------------------------------------------- main
 
 def main():
+    # stdout carries exactly ONE line, the JSON: everything else that may write to file descriptor 1 (RCCL prints
+    # its version banner there when a communicator is created) is sent to stderr for the whole run
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
@@ -298,7 +302,8 @@ def main():
     else:
         line = run_cfg2(args, torch, dist, R, rank, local_rank, world, dev, use_dist, main_stream, fence)
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        json_out.write(json.dumps(line) + "\n")
+        json_out.flush()
     if use_dist:
         dist.destroy_process_group()
 

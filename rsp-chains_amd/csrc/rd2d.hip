@@ -451,11 +451,20 @@ static hipError_t launch_rd2d_chunk(const Rd2dLaunch& a, uint32_t ch0, uint32_t 
   const bool spec = a.regs.R == 8 && a.regs.G == 2 && a.ref_d == 8 && a.guard_d == 2;  // cfg 3 / cfg 5
   if (spec && !a.force_tiled_cfar) {
     const uint32_t strips = (nr + walk_outw(10) - 1) / walk_outw(10);
-    // 64 rows per wave: 32 measures the same, 128 is 6 % slower (fewer waves to hide the row latency)
-    constexpr uint32_t SEG = 64;
-    hipLaunchKernelGGL((cfar2d_walk_kernel<8, 2, 8, 2, SEG>), dim3(n_ch * strips * (nd / SEG / 4)), dim3(256), 0,
-                       a.stream, a.scratch_mag, out, nd, nr, strips, a.regs.edge, kA, kB, a.det_list, a.det_cap,
-                       a.det_counters, ch0);
+    // rows per wave: every segment re-reads 2 HD + 1 = 21 halo rows, so 64 rows cost 1.33x the map in reads, 128 rows 1.16x
+#ifndef RSP_WALK_SEG
+#define RSP_WALK_SEG 64
+#endif
+    constexpr uint32_t SEG = RSP_WALK_SEG;
+    if (nd % (SEG * 4) == 0) {
+      hipLaunchKernelGGL((cfar2d_walk_kernel<8, 2, 8, 2, SEG>), dim3(n_ch * strips * (nd / SEG / 4)), dim3(256), 0,
+                         a.stream, a.scratch_mag, out, nd, nr, strips, a.regs.edge, kA, kB, a.det_list, a.det_cap,
+                         a.det_counters, ch0);
+    } else {
+      hipLaunchKernelGGL((cfar2d_walk_kernel<8, 2, 8, 2, 64>), dim3(n_ch * strips * (nd / 64 / 4)), dim3(256), 0,
+                         a.stream, a.scratch_mag, out, nd, nr, strips, a.regs.edge, kA, kB, a.det_list, a.det_cap,
+                         a.det_counters, ch0);
+    }
     return hipGetLastError();
   }
   auto k = cfar2d_kernel<-1, -1, -1, -1>;
