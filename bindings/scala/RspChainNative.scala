@@ -38,8 +38,9 @@ object RspChainNative {
         c.CFARAlgorithm match { case CACFARType => 0; case GOSCFARType => 1; case GOSCACFARType => 2 },
         c.numMulPipes, 0 /* edgeMode zero */).foreach(b.putInt)
     Seq(p.fftAddress, p.magAddress, p.cfarAddress).foreach { a => b.putInt(a.base.toInt); b.putInt(a.mask.toInt) }
-    Seq(p.beatBytes, dtype, device, 0, 0, 0).foreach(b.putInt)
-    (0 until 8).foreach(_ => b.putInt(0))
+    Seq(p.beatBytes, dtype, device, 0, 0, 0).foreach(b.putInt)   // dopplerPoints, refDoppler, guardDoppler = 0: the 1-D chain
+    Seq(0, 0).foreach(b.putInt)                                    // window, windowDoppler = RSP_WINDOW_NONE
+    (0 until 6).foreach(_ => b.putInt(0))                          // reserved[6]
     b
   }
 }
@@ -53,9 +54,11 @@ class GpuFftMagCfarChain(params: FftMagCfarVanillaParameters) {
     require(axi4StreamIn.length % fftSize == 0)
     val in = ByteBuffer.allocateDirect(4 * axi4StreamIn.length).order(ByteOrder.LITTLE_ENDIAN)
     axi4StreamIn.foreach(in.putInt)
-    val out = ByteBuffer.allocateDirect(4 * axi4StreamIn.length).order(ByteOrder.LITTLE_ENDIAN)
+    // CFARParams.sendCut = true widens the output beat to 64 bits: two words per cell, {word, cut} (include/rspchain.h)
+    val wordsPerCell = if (params.cfarParams.sendCut) 2 else 1
+    val out = ByteBuffer.allocateDirect(4 * wordsPerCell * axi4StreamIn.length).order(ByteOrder.LITTLE_ENDIAN)
     RspChainNative.process(h, in, axi4StreamIn.length / fftSize, out)
-    Seq.tabulate(axi4StreamIn.length)(i => out.getInt(4 * i))
+    Seq.tabulate(wordsPerCell * axi4StreamIn.length)(i => out.getInt(4 * i))
   }
   def close(): Unit = RspChainNative.destroy(h)
 }
