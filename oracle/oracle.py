@@ -42,7 +42,7 @@ class OrcFCfg(C.Structure):
 class OrcRdCfg(C.Structure):
     _fields_ = [("log2nr", C.c_int32), ("log2nd", C.c_int32), ("mag_mode", C.c_int32),
                 ("scaler", C.c_double)] + [(n, C.c_int32) for n in (
-                    "ref_r", "ref_d", "guard_r", "guard_d", "edge", "window_r", "window_d")]
+                    "ref_r", "ref_d", "guard_r", "guard_d", "edge", "window_r", "window_d", "cfar_mode")]
 
 
 class OrcStimCfg(C.Structure):

@@ -590,9 +590,21 @@ void orc_rd_f32in(const float* in, size_t n_ch, const orc_rdcfg* c, double* thr,
     for (int d = 0; d < nd; d++) {
       for (int r = 0; r < nr; r++) {
         int cd = d + hd, cr = r + hr;
-        double outer = BOX(cd - hd, cd + hd, cr - hr, cr + hr);
-        double inner = BOX(cd - c->guard_d, cd + c->guard_d, cr - c->guard_r, cr + c->guard_r);
-        double t = c->scaler * (outer - inner) / count;
+        double t;
+        if (c->cfar_mode == ORC_CFAR_CA) {
+          double outer = BOX(cd - hd, cd + hd, cr - hr, cr + hr);
+          double inner = BOX(cd - c->guard_d, cd + c->guard_d, cr - c->guard_r, cr + c->guard_r);
+          t = c->scaler * (outer - inner) / count;
+        } else {
+          int gd = c->guard_d, gr = c->guard_r;
+          double lag = BOX(cd - hd, cd + hd, cr - hr, cr - 1) - (gr > 0 ? BOX(cd - gd, cd + gd, cr - gr, cr - 1) : 0.0) +
+                       BOX(cd - hd, cd - gd - 1, cr, cr);
+          double lead = BOX(cd - hd, cd + hd, cr + 1, cr + hr) - (gr > 0 ? BOX(cd - gd, cd + gd, cr + 1, cr + gr) : 0.0) +
+                        BOX(cd + gd + 1, cd + hd, cr, cr);
+          double half = 0.5 * count;
+          double st = c->cfar_mode == ORC_CFAR_GO ? (lag > lead ? lag : lead) : (lag < lead ? lag : lead);
+          t = c->scaler * st / half;
+        }
         size_t o = map * (size_t)ch + (size_t)d * (size_t)nr + (size_t)r;
         double cut = m[(size_t)d * (size_t)nr + (size_t)r];
         thr[o] = t;

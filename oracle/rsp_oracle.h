@@ -153,7 +153,9 @@ void orc_chain_f32in(const float* in, size_t n_frames, const orc_fcfg* c, double
  * (log2nr), Doppler FFT over d (log2nd), each scaled 1/N; magnitude; 2-D
  * CA-CFAR with training band (ref_r, ref_d) beyond guard band (guard_r,
  * guard_d), cyclic in Doppler, edge policy `edge` in range.  Output maps are
- * [ch][d][r]. */
+ * [ch][d][r].  GO / SO (BUILD-DEFINED, spec section 6): the training region is split into a LAGGING half (cells at
+ * smaller range than the CUT, + the cells of the CUT's own column at smaller Doppler) and the mirror-image LEADING
+ * half; statistic per half = its sum / (count / 2); CA = their mean (= sum / count), GO = max, SO = min. */
 typedef struct orc_rdcfg {
   int32_t log2nr, log2nd;
   int32_t mag_mode;
@@ -161,6 +163,7 @@ typedef struct orc_rdcfg {
   int32_t ref_r, ref_d, guard_r, guard_d;
   int32_t edge;
   int32_t window_r, window_d; /* ORC_WIN_*: windows over fast / slow time (build extension) */
+  int32_t cfar_mode;          /* ORC_CFAR_CA / _GO / _SO over the lagging / leading halves of the training region */
 } orc_rdcfg;
 void orc_rd_f32in(const float* in, size_t n_ch, const orc_rdcfg* c, double* thr, uint8_t* peak,
                   double* margin, double* mag_out /* may be NULL */, int n_threads);

@@ -135,7 +135,8 @@ template <int SRR, int SGR, int SRD, int SGD>
 __global__ void __launch_bounds__(256)
 cfar2d_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_t nd, uint32_t nr,
               int ref_r_rt, int guard_r_rt, int ref_d_rt, int guard_d_rt, int edge, float kA, float kB,
-              rsp_detection* __restrict__ det_list, uint32_t det_cap, uint32_t* __restrict__ det_counters, uint32_t ch_base) {
+              rsp_detection* __restrict__ det_list, uint32_t det_cap, uint32_t* __restrict__ det_counters, uint32_t ch_base,
+              int mode) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int ref_r = SRR >= 0 ? SRR : ref_r_rt, guard_r = SGR >= 0 ? SGR : guard_r_rt;
   const int ref_d = SRD >= 0 ? SRD : ref_d_rt, guard_d = SGD >= 0 ? SGD : guard_d_rt;
@@ -148,6 +149,9 @@ cfar2d_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_
   // array short is what lets four workgroups share a CU's LDS
   const int ri_first = hd - guard_d, ri_rows = kTD + 2 * guard_d + 1;
   float* ri = ro + (RH + 1) * (kTR + 1);            // [ri_rows][kTR + 1], row dd at index dd - ri_first
+  // GO / SO (mode 1 / 2): the same sums over the LAGGING half of each row window (columns c - h .. c - 1)
+  float* roL = ri + ri_rows * (kTR + 1);            // [RH][kTR + 1]
+  float* riL = roL + (RH + 1) * (kTR + 1);          // [ri_rows][kTR + 1]
   const int tid = threadIdx.x;
   const uint32_t tiles_r = nr / kTR, tiles_d = nd / kTD;
   const uint32_t ch = blockIdx.x / (tiles_r * tiles_d);
@@ -194,12 +198,28 @@ cfar2d_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_
     float* po = ro + dd * (kTR + 1) + c0;
     const bool want_i = dd >= ri_first && dd < ri_first + ri_rows;
     float* pi = ri + (want_i ? dd - ri_first : 0) * (kTR + 1) + c0;
+    if (mode == 0) {
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      po[c] = so;
-      if (want_i) pi[c] = si;
-      so += row[c + hr + 1] - row[c - hr];
-      si += row[c + guard_r + 1] - row[c - guard_r];
+      for (int c = 0; c < 16; ++c) {
+        po[c] = so;
+        if (want_i) pi[c] = si;
+        so += row[c + hr + 1] - row[c - hr];
+        si += row[c + guard_r + 1] - row[c - guard_r];
+      }
+    } else {
+      float* pol = roL + dd * (kTR + 1) + c0;
+      float* pil = riL + (want_i ? dd - ri_first : 0) * (kTR + 1) + c0;
+      float sol = so2, sil = si2;  // so2 / si2 = the sums over columns -h .. -1 computed above
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        po[c] = so;
+        pol[c] = sol;
+        if (want_i) { pi[c] = si; pil[c] = sil; }
+        so += row[c + hr + 1] - row[c - hr];
+        si += row[c + guard_r + 1] - row[c - guard_r];
+        sol += row[c] - row[c - hr];
+        sil += row[c] - row[c - guard_r];
+      }
     }
   }
   __syncthreads();
@@ -218,9 +238,27 @@ cfar2d_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_
     so += so2;
     si += si2;
     uint32_t* dst = out + ((size_t)ch * nd + d0 + dseg) * nr + r0 + c;
+    // GO / SO: column sums of the lagging-half row sums + the cells of the CUT's own column above the guard
+    const float* col = roL + (dseg + hd) * (kTR + 1) + c;
+    const float* cil = riL + (dseg + hd - ri_first) * (kTR + 1) + c;
+    const float* mcol = m + (dseg + hd) * MS + c + hr;  // mcol[k MS] = the CUT column at output row dseg + k
+    float sol = 0.f, sil = 0.f, up = 0.f;
+    if (mode != 0) {
+      for (int k = -hd; k <= hd; ++k) sol += col[k * (kTR + 1)];
+      for (int k = -guard_d; k <= guard_d; ++k) sil += cil[k * (kTR + 1)];
+      for (int k = -hd; k < -guard_d; ++k) up += mcol[k * MS];
+    }
+    const float kAh = 2.0f * kAc;  // a half holds count / 2 cells
 #pragma unroll
     for (int j = 0; j < kTD / 4; ++j) {
-      const float thr = __fmaf_rn(so - si, kAc, kB);
+      float thr = __fmaf_rn(so - si, kAc, kB);
+      if (mode != 0) {
+        const float lag = sol - sil + up, lead = (so - si) - lag;
+        thr = __fmaf_rn(mode == 1 ? fmaxf(lag, lead) : fminf(lag, lead), kAh, kB);
+        sol += col[(j + hd + 1) * (kTR + 1)] - col[(j - hd) * (kTR + 1)];
+        sil += cil[(j + guard_d + 1) * (kTR + 1)] - cil[(j - guard_d) * (kTR + 1)];
+        up += mcol[(j - guard_d) * MS] - mcol[(j - hd) * MS];
+      }
       const float cut = m[(dseg + j + hd) * MS + c + hr];
       const uint32_t wd = (__float_as_uint(thr) & ~1u) | (uint32_t)(cut > thr);
       dst[(size_t)j * nr] = wd;
@@ -270,7 +308,7 @@ constexpr int walk_lb(int hr) { return (hr + 2) / 2; }
 constexpr int walk_le(int hr) { return (126 - hr) / 2; }
 constexpr int walk_outw(int hr) { return 2 * (walk_le(hr) - walk_lb(hr) + 1); }
 
-template <int RR, int GR, int RD, int GD, int SEG>
+template <int RR, int GR, int RD, int GD, int SEG, int MODE>
 __global__ void __launch_bounds__(256)
 cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_t nd, uint32_t nr,
                    uint32_t strips, int edge, float kA, float kB,
@@ -320,6 +358,12 @@ cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, ui
   for (int p = 1; p <= 2 * HD; ++p) vo += ring[p];
 #pragma unroll
   for (int p = HD - GD + 1; p <= HD + GD; ++p) vi += ring[p];
+  f32x2 vup = {0.f, 0.f};  // GO / SO: the RD rows above the guard band (the CUT's own column belongs to a half by Doppler side)
+  if constexpr (MODE != 0) {
+#pragma unroll
+    for (int p = 0; p < RD; ++p) vup += ring[p];
+  }
+  const float kAh = 2.0f * kAc;
   for (int chunk = 0; chunk < SEG / RING; ++chunk) {
 #pragma unroll
     for (int u = 0; u < RING; ++u) {
@@ -332,7 +376,19 @@ cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, ui
       const f32x2 si = {prefix_at<GR>(pi0, pi1, lane) - prefix_at<-GR - 1>(pi0, pi1, lane),
                         prefix_at<1 + GR>(pi0, pi1, lane) - prefix_at<-GR>(pi0, pi1, lane)};
       const f32x2 cut = ring[(u + HD) % RING];
-      const float t0 = __fmaf_rn(so.x - si.x, kAc, kB), t1 = __fmaf_rn(so.y - si.y, kAc, kB);
+      float t0, t1;
+      if constexpr (MODE == 0) {
+        t0 = __fmaf_rn(so.x - si.x, kAc, kB);
+        t1 = __fmaf_rn(so.y - si.y, kAc, kB);
+      } else {
+        // lagging half: columns c - H .. c - 1 of the box sums (the prefix at c - 1 is this lane's own) + the rows of
+        // column c above the guard; leading half = the rest of the training region
+        const f32x2 lago = {(po0 - vo.x) - prefix_at<-HR - 1>(po0, po1, lane), po0 - prefix_at<-HR>(po0, po1, lane)};
+        const f32x2 lagi = {(pi0 - vi.x) - prefix_at<-GR - 1>(pi0, pi1, lane), pi0 - prefix_at<-GR>(pi0, pi1, lane)};
+        const f32x2 lag = (lago - lagi) + vup, lead = (so - si) - lag;
+        t0 = __fmaf_rn(MODE == 1 ? fmaxf(lag.x, lead.x) : fminf(lag.x, lead.x), kAh, kB);
+        t1 = __fmaf_rn(MODE == 1 ? fmaxf(lag.y, lead.y) : fminf(lag.y, lead.y), kAh, kB);
+      }
       u32x2 wd;
       wd.x = (__float_as_uint(t0) & ~1u) | (uint32_t)(cut.x > t0);
       wd.y = (__float_as_uint(t1) & ~1u) | (uint32_t)(cut.y > t1);
@@ -349,6 +405,7 @@ cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, ui
       }
       vo += ring[(u + SPAN - 1) % RING] - ring[u];
       vi += ring[(u + HD + GD + 1) % RING] - ring[(u + HD - GD) % RING];
+      if constexpr (MODE != 0) vup += ring[(u + RD) % RING] - ring[u];
       // keep every row's load at the top of its own step: the scheduler would otherwise sink the
       // loads next to their first use, 10 rows later, and drain the prefetch pipeline
       __builtin_amdgcn_sched_barrier(0);
@@ -444,8 +501,8 @@ static hipError_t launch_rd2d_chunk(const Rd2dLaunch& a, uint32_t ch0, uint32_t 
   }
   if (e != hipSuccess) return e;
   const int hr = a.regs.R + a.regs.G, hd = a.ref_d + a.guard_d;
-  const size_t lds = 4 * ((size_t)(kTD + 2 * hd) * ((kTR + 2 * hr) | 1) + (size_t)(kTD + 2 * hd + 1) * (kTR + 1) +
-                          (size_t)(kTD + 2 * a.guard_d + 1) * (kTR + 1));
+  const size_t lds = 4 * ((size_t)(kTD + 2 * hd) * ((kTR + 2 * hr) | 1) +
+                          (a.regs.cfar_mode ? 2 : 1) * ((size_t)(kTD + 2 * hd + 1) * (kTR + 1) + (size_t)(kTD + 2 * a.guard_d + 1) * (kTR + 1)));
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const float kA = a.regs.linear ? a.regs.scaler_f : 1.0f, kB = a.regs.linear ? 0.0f : a.regs.scaler_f;
   const bool spec = a.regs.R == 8 && a.regs.G == 2 && a.ref_d == 8 && a.guard_d == 2;  // cfg 3 / cfg 5
@@ -456,15 +513,14 @@ static hipError_t launch_rd2d_chunk(const Rd2dLaunch& a, uint32_t ch0, uint32_t 
 #define RSP_WALK_SEG 64
 #endif
     constexpr uint32_t SEG = RSP_WALK_SEG;
-    if (nd % (SEG * 4) == 0) {
-      hipLaunchKernelGGL((cfar2d_walk_kernel<8, 2, 8, 2, SEG>), dim3(n_ch * strips * (nd / SEG / 4)), dim3(256), 0,
-                         a.stream, a.scratch_mag, out, nd, nr, strips, a.regs.edge, kA, kB, a.det_list, a.det_cap,
-                         a.det_counters, ch0);
-    } else {
-      hipLaunchKernelGGL((cfar2d_walk_kernel<8, 2, 8, 2, 64>), dim3(n_ch * strips * (nd / 64 / 4)), dim3(256), 0,
-                         a.stream, a.scratch_mag, out, nd, nr, strips, a.regs.edge, kA, kB, a.det_list, a.det_cap,
-                         a.det_counters, ch0);
-    }
+    const dim3 grid(n_ch * strips * (nd / SEG / 4));
+#define RSP_WALK(MODE)                                                                                              \
+  hipLaunchKernelGGL((cfar2d_walk_kernel<8, 2, 8, 2, SEG, MODE>), grid, dim3(256), 0, a.stream, a.scratch_mag, out, \
+                     nd, nr, strips, a.regs.edge, kA, kB, a.det_list, a.det_cap, a.det_counters, ch0)
+    if (a.regs.cfar_mode == 0) RSP_WALK(0);
+    else if (a.regs.cfar_mode == 1) RSP_WALK(1);
+    else RSP_WALK(2);
+#undef RSP_WALK
     return hipGetLastError();
   }
   auto k = cfar2d_kernel<-1, -1, -1, -1>;
@@ -473,7 +529,7 @@ static hipError_t launch_rd2d_chunk(const Rd2dLaunch& a, uint32_t ch0, uint32_t 
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3(n_ch * (nr / kTR) * (nd / kTD)), dim3(256), lds, a.stream, a.scratch_mag, out,
                      nd, nr, a.regs.R, a.regs.G, a.ref_d, a.guard_d, a.regs.edge, kA, kB, a.det_list, a.det_cap,
-                     a.det_counters, ch0);
+                     a.det_counters, ch0, a.regs.cfar_mode);
   return hipGetLastError();
 }
 

@@ -249,8 +249,7 @@ int check_regs(const rsp_chain* c) {
   }
   if (p.dopplerPoints) {
     if (m != m_max) return fail(RSP_ERR_UNSUPPORTED, "2-D chain: run-time FFT size must equal numPoints");
-    if (c->cfar[kMode] != RSP_MODE_CA) return fail(RSP_ERR_UNSUPPORTED, "2-D chain: cfarMode must be Cell Averaging");
-    if (uses_gos(c) || c->cfar[kPeakGrouping]) return fail(RSP_ERR_UNSUPPORTED, "2-D chain: CA without peak grouping only");
+    if (uses_gos(c) || c->cfar[kPeakGrouping]) return fail(RSP_ERR_UNSUPPORTED, "2-D chain: CA / GO / SO without peak grouping only");
     if (R + G > 32) return fail(RSP_ERR_UNSUPPORTED, "2-D chain: range training + guard half-width %d exceeds the 32-cell tile halo", R + G);
   }
   if (c->cfar[kScaler] > 0xFFFFu) return fail(RSP_ERR_INVALID, "thresholdScaler register = 0x%x exceeds protoScaler's 16 bits", c->cfar[kScaler]);

@@ -53,6 +53,31 @@ def test_rd2d_against_oracle(gpu, nr, nd, edge):
         assert words[ch, db, rb] & 1
 
 
+@pytest.mark.parametrize("mode", ["Greatest Of", "Smallest Of"])
+@pytest.mark.parametrize("rr,gr,rd,gd,edge", [(8, 2, 8, 2, "zero"), (8, 2, 8, 2, "wrap"), (4, 1, 5, 3, "zero"), (16, 3, 4, 0, "wrap")])
+def test_rd2d_go_so(gpu, mode, rr, gr, rd, gd, edge):
+    """2-D GO / SO (build-defined: docs/FIXED_POINT_SPEC.md section 6): greatest / smallest of the means of the lagging
+    and the leading half of the training region.  Compile-time windows take the strip walker, the others the tiled kernel."""
+    nr, nd, n_ch = 1024, 256, 2
+    params = rd_params(nr, nd, ref=rd, guard=gd, edge=edge)
+    rt = R.RunTimeRspChainParams(fftSize=nr, CFARMode=mode, refWindowSize=rr, guardWindowSize=gr if gr else 1, divSum=4,
+                                 thresholdScaler=4.0)
+    if gr == 0:
+        pytest.skip("guardWindowSize register must be > 0 (RspChainVanillaTester.scala:51)")
+    x, where = targets(n_ch, nd, nr, seed=7 + rr)
+    with R.FftMagCfarChainVanilla(params) as dut:
+        dut.configure(rt)
+        words = dut.stream(x)
+    cfg = O.OrcRdCfg(log2nr=10, log2nd=8, mag_mode=O.MAG_JPL, scaler=4.0, ref_r=rr, ref_d=rd, guard_r=gr, guard_d=gd,
+                     edge=1 if edge == "wrap" else 0, cfar_mode=O.CFAR_GO if mode == "Greatest Of" else O.CFAR_SO)
+    thr, peak, margin, mag = O.rd_f32(x, cfg, want_mag=True)
+    compare_f32(words.reshape(n_ch, -1), thr.reshape(n_ch, -1), peak.reshape(n_ch, -1), margin.reshape(n_ch, -1),
+                mag.reshape(n_ch, -1))
+    ca = O.rd_f32(x, O.OrcRdCfg(log2nr=10, log2nd=8, mag_mode=O.MAG_JPL, scaler=4.0, ref_r=rr, ref_d=rd, guard_r=gr,
+                                guard_d=gd, edge=1 if edge == "wrap" else 0))[0]
+    assert np.all(thr >= ca - 1e-12) if mode == "Greatest Of" else np.all(thr <= ca + 1e-12)   # GO >= CA >= SO
+
+
 @pytest.mark.parametrize("wr,wd", [("hann", None), (None, "hamming"), ("blackman", "hann")])
 def test_rd2d_windows(gpu, wr, wd):
     """Pre-FFT windows over fast time (range) and slow time (Doppler): SURVEY 8f-n4, no reference item."""
@@ -209,7 +234,8 @@ def test_rd2d_detection_list(gpu, tiled):
 def test_rd2d_rejects_what_it_does_not_implement(gpu):
     params = rd_params(1024, 512)
     with R.FftMagCfarChainVanilla(params) as dut:
-        dut.configure(R.RunTimeRspChainParams(fftSize=1024, CFARMode="Greatest Of", refWindowSize=8, guardWindowSize=2, divSum=4))
+        dut.configure(R.RunTimeRspChainParams(fftSize=1024, CFARMode="Cell Averaging", refWindowSize=8, guardWindowSize=2, divSum=4,
+                                              peakGrouping=1))
         with pytest.raises(NotImplementedError):
             dut.check()
     with pytest.raises(NotImplementedError):
