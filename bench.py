@@ -408,6 +408,10 @@ def run_cfg5(args, torch, dist, R, rank, local_rank, world, dev, use_dist, main_
                    "sharding": "contiguous channels per rank (dist.shard_range); no data-path collective"},
         "gather": {"ms_per_collective_alone": gather_ms, "ms_per_step_without_gather": sec_ng / args.steps * 1e3,
                    "bytes_per_rank": (cap + 1) * 16},
+        "scaling_note": ("N > 1 lines run BASELINE.json configs[4] (64 Rx, fixed total work); the N = 1 line's headline is configs[1] "
+                         "(a different, lighter workload per cell), so scaling efficiency is value(N) / (N/8 x 8 x the N = 1 line's "
+                         "extra.cfg5_share.value), i.e. against the same 8-Rx-per-GPU share measured on one GPU"),
+        "per_gpu_value": cells_total * args.steps / sec / world,
         "roofline": roofline(w["kernel"], kms, 28.0 * n_ch * nd * nr),
     }
 
