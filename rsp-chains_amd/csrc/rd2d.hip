@@ -4,15 +4,17 @@
 // (SURVEY F5); this is BASELINE.json configs[2] / configs[4], specified by
 // oracle/rsp_oracle.c::orc_rd_f32in.  A channel's map is [doppler d][range r], row-major.
 //
-//   range_fft_kernel   rows: FFT over r (contiguous), complex out in natural order  (8 R + 8 W)
-//   doppler_mag_kernel columns: FFT over d for 16 adjacent range bins per workgroup so that
-//                      every global access is a 128-B (in) / 64-B (out) segment; |.| out (8 R + 4 W)
+//   range_fft_kernel   rows: FFT over r (contiguous in), complex out in tiles of 16 range bins  (8 R + 8 W)
+//   doppler_mag_kernel columns: FFT over d for 8 / 16 adjacent range bins per workgroup = one contiguous
+//                      block of the tiled map; |.| out in the same tiling                     (8 R + 4 W)
 //   cfar2d_walk_kernel (windows of cfg 3 / 5, compile-time) one wave walks a 128-column strip down
-//                      the Doppler axis: register ring of rows, running column sums, DPP prefix +
-//                      ds_bpermute for the row sums; no LDS memory, no barriers       (4 R + 4 W)
+//                      the Doppler axis: register ring of rows, running column sums, cross-lane window
+//                      sums for the row direction; no LDS memory, no barriers                  (4 R + 4 W)
 //   cfar2d_kernel      (any run-time windows) tile + halo in LDS, separable sliding box sums
-// = 36 B/cell against the 28 B/cell a fully fused Doppler+CFAR pass would need (the CFAR halo
-// crosses workgroup tiles in range; fusing it means recomputing halo columns' FFTs).
+// = 36 B/cell against the 28 B/cell a fully fused Doppler+CFAR pass would need.  That fusion was designed
+// and dropped: the CFAR halo crosses workgroup tiles in range, so the fused workgroup has to
+// keep 2 (ref + guard) + 1 = 21 magnitude columns x all Doppler bins next to its FFT image: 64 KiB + 32 KiB at
+// 512 Doppler bins (one workgroup per CU), 128 KiB + 64 KiB at 1024 (does not fit 160 KiB).
 #include <hip/hip_runtime.h>
 #include <float.h>
 
@@ -31,10 +33,28 @@ __device__ __forceinline__ float mag2d(f32x2 z, int mode) {
   return __log2f(fmaxf(jpl, FLT_MIN));
 }
 
+// Layout of the two intermediate maps (range spectra, magnitudes) of one channel.  Row-major [d][r] makes the Doppler
+// pass walk the map at a 64-KB pitch at 8192 range bins (HBM rows and channels see a power-of-two stride:
+// 264 us at 8 x 8192 x 1024); tiles of 16 range bins, [r / 16][d][r % 16], give every Doppler workgroup ONE
+// contiguous block (193 us), the range pass still writes whole 128-B lines and the CFAR walker reads 64-B segments of
+// sequential streams.  RSP_RD_TILE=0 builds the row-major layout for A/B runs.
+#ifndef RSP_RD_TILE
+#define RSP_RD_TILE 16
+#endif
+#ifndef RSP_RD_MAGTILE
+#define RSP_RD_MAGTILE RSP_RD_TILE
+#endif
+constexpr uint32_t kMapTile = RSP_RD_TILE, kMagTile = RSP_RD_MAGTILE;  // range spectra, magnitudes
+template <uint32_t TILE>
+__host__ __device__ __forceinline__ size_t map_index(uint32_t d, uint32_t r, uint32_t nd, uint32_t nr) {
+  if constexpr (TILE == 0) return (size_t)d * nr + r;
+  else return ((size_t)(r / TILE) * nd + d) * TILE + (r % TILE);
+}
+
 // ---------------------------------------------------------------- range pass (rows)
 template <int M>
 __global__ void __launch_bounds__(wg_size(M))
-range_fft_kernel(const f32x2* __restrict__ in, f32x2* __restrict__ out, uint32_t n_rows,
+range_fft_kernel(const f32x2* __restrict__ in, f32x2* __restrict__ out, uint32_t n_rows, uint32_t nd,
                  const f32x2* __restrict__ tw, const float* __restrict__ win) {
   constexpr int N = 1 << M, T = threads_per_frame(M), FPW = frames_per_wg(M);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -55,11 +75,16 @@ range_fft_kernel(const f32x2* __restrict__ in, f32x2* __restrict__ out, uint32_t
   constexpr int NP = plan_np(M), WL = plan_w(M, NP - 1);
   const float scale = 1.0f / (float)N;
   if (!live) return;
-  f32x2* dst = out + (size_t)row * N + tau;
+  // bins c + tau with c a multiple of T >= 16: the tile index splits into a per-lane and a per-register part
+  static_assert(kMapTile == 0 || T % kMapTile == 0, "a register's bins start on a tile boundary");
+  const uint32_t ch = row / nd, d = row % nd;
+  f32x2* dst = out + (size_t)ch * nd * N + map_index<kMapTile>(d, tau, nd, N);
+  const size_t step = kMapTile ? (size_t)nd : 1;  // elements between bins c and c + 1 tile-columns apart, per bin
 #pragma unroll
   for (int g = 0; g < (16 >> WL); ++g) {
 #pragma unroll
-    for (int p = 0; p < (1 << WL); ++p) dst[(bitrev_c(p, WL) << (M - WL)) + g * T] = x[g * (1 << WL) + p] * scale;
+    for (int p = 0; p < (1 << WL); ++p)
+      dst[(size_t)((bitrev_c(p, WL) << (M - WL)) + g * T) * step] = x[g * (1 << WL) + p] * scale;
   }
 }
 
@@ -67,7 +92,13 @@ range_fft_kernel(const f32x2* __restrict__ in, f32x2* __restrict__ out, uint32_t
 #ifndef RSP_DOPPLER_COLS10
 #define RSP_DOPPLER_COLS10 8
 #endif
-constexpr int kColsPerWg(int MD) { return MD >= 10 ? (RSP_DOPPLER_COLS10) : 16; }
+#ifndef RSP_DOPPLER_COLS9
+#define RSP_DOPPLER_COLS9 16
+#endif
+#ifndef RSP_DOPPLER_XCDMAP
+#define RSP_DOPPLER_XCDMAP (C * 8 < 128)
+#endif
+constexpr int kColsPerWg(int MD) { return MD >= 10 ? (RSP_DOPPLER_COLS10) : MD == 9 ? (RSP_DOPPLER_COLS9) : 16; }
 // LDS bytes per column: the padded FFT image + 32 B so that adjacent columns start 8 banks apart
 constexpr int kColBytes(int MD) { return 8 * fft_image_slots(MD) + 32; }
 
@@ -83,27 +114,38 @@ doppler_mag_kernel(const f32x2* __restrict__ in, float* __restrict__ mag, uint32
   // workgroups are dealt round-robin to the 8 XCDs: give each XCD a contiguous run of column tiles, so
   // that the two 8-column tiles sharing a 128-B line meet in the same L2 (-25 % at 1024 Doppler bins;
   // with 16 columns a tile reads whole lines and the plain order is the faster one)
-  const uint32_t tile = (C * 8 < 128 && gridDim.x % 8 == 0) ? (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8
+  const uint32_t tile = ((RSP_DOPPLER_XCDMAP) && gridDim.x % 8 == 0) ? (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8
                                                             : blockIdx.x;
   const uint32_t ch = tile / tiles_per_ch, r0 = (tile % tiles_per_ch) * C;
   f32x2* buf = reinterpret_cast<f32x2*>(smem + (size_t)fl * kColBytes(MD));
-  const size_t col = (size_t)ch * ND * nr + r0 + fl;  // element index of (ch, d = 0, r)
-  const f32x2* src = in + col + (size_t)first_sample<MD>(tau) * nr;
+  // element index of (ch, d = 0, r) and the distance between Doppler rows, in each of the two maps
+  const size_t col = (size_t)ch * ND * nr + map_index<kMapTile>(0, r0 + fl, ND, nr);
+  const size_t mcol = (size_t)ch * ND * nr + map_index<kMagTile>(0, r0 + fl, ND, nr);
+  const uint32_t pitch = kMapTile ? kMapTile : nr, mpitch = kMagTile ? kMagTile : nr;
+  const f32x2* src = in + col + (size_t)first_sample<MD>(tau) * pitch;
   f32x2 x[16];
   if (win) {  // slow-time window
     const float* wsrc = win + first_sample<MD>(tau);
-    fft_f32_frame<MD>([&](int d) { const float wv = wsrc[d]; return src[(size_t)d * nr] * f32x2{wv, wv}; }, tau, buf, tw, x);
+    fft_f32_frame<MD>([&](int d) { const float wv = wsrc[d]; return src[(size_t)d * pitch] * f32x2{wv, wv}; }, tau, buf, tw, x);
   } else {
-    fft_f32_frame<MD>([&](int d) { return src[(size_t)d * nr]; }, tau, buf, tw, x);
+#ifdef RSP_ABL_DOP_L2  // ablation builds: rows 0..15 only (L2-resident source)
+    fft_f32_frame<MD>([&](int d) { return src[(size_t)(d & 15) * pitch]; }, tau, buf, tw, x);
+#else
+    fft_f32_frame<MD>([&](int d) { return src[(size_t)d * pitch]; }, tau, buf, tw, x);
+#endif
   }
   constexpr int NP = plan_np(MD), WL = plan_w(MD, NP - 1);
   const float scale = 1.0f / (float)ND;
-  float* dst = mag + col;
+  float* dst = mag + mcol;
+#ifdef RSP_ABL_DOP_NOSTORE
+  if (mag_mode != 77) dst = nullptr;
+  if (mag_mode == 77)
+#endif
 #pragma unroll
   for (int g = 0; g < (16 >> WL); ++g) {
 #pragma unroll
     for (int p = 0; p < (1 << WL); ++p)
-      dst[(size_t)bin_of<MD>(tau, g, p) * nr] = mag2d(x[g * (1 << WL) + p] * scale, mag_mode);
+      dst[(size_t)bin_of<MD>(tau, g, p) * mpitch] = mag2d(x[g * (1 << WL) + p] * scale, mag_mode);
   }
 }
 
@@ -172,7 +214,7 @@ cfar2d_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_
       for (int u = 0; u < 16; ++u) {
         const int dd = base + 2 * u;
         const int d = (d0 - hd + dd + (int)nd) & ((int)nd - 1);  // Doppler cyclic (nd is a power of two)
-        v[u] = (inside && dd < RH) ? map[(size_t)d * nr + r] : 0.f;
+        v[u] = (inside && dd < RH) ? map[map_index<kMagTile>((uint32_t)d, (uint32_t)r, nd, nr)] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
@@ -334,14 +376,23 @@ cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, ui
       __builtin_amdgcn_make_buffer_rsrc(out + (size_t)ch * nd * nr, 0, (int)map_bytes, (int)kRsrc3);
   const bool readable = edge || (col >= 0 && col < (int)nr);
   const bool owner = lane >= LB && lane <= LE && col < (int)nr;
-  const uint32_t voff_in = readable ? (uint32_t)(col & ((int)nr - 1)) * 4u : kOob;
+  const uint32_t voff_in = readable ? (uint32_t)map_index<kMagTile>(0, (uint32_t)(col & ((int)nr - 1)), nd, nr) * 4u : kOob;
+  const uint32_t row_bytes = (kMagTile ? kMagTile : nr) * 4u;  // address step between Doppler rows of the magnitude map
+#ifdef RSP_ABL_WALK_NOSTORE  // ablation builds (tools/ablate_rd.sh): never defined in the product
+  const uint32_t voff_out = kOob;
+#else
   const uint32_t voff_out = owner ? (uint32_t)col * 4u : kOob;
+#endif
   const float count = (float)((2 * HR + 1) * (2 * HD + 1) - (2 * GR + 1) * (2 * GD + 1));
   const float kAc = kA / count;
   // stream row p <-> map row d0 - HD + p (Doppler cyclic)
   auto load_row = [&](int p) -> f32x2 {
+#ifdef RSP_ABL_WALK_ROW0
+    const uint32_t d = (uint32_t)(p & 31);
+#else
     const uint32_t d = (uint32_t)((d0 - HD + p) & ((int)nd - 1));
-    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_in, voff_in, d * nr * 4u, 0));
+#endif
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_in, voff_in, d * row_bytes, 0));
   };
   // fused detection list: peaks are staged in a wave-private LDS buffer during the walk (LDS atomics
   // only: a vector-memory atomic inside the walk, even in a never-taken branch, makes the wait-count
@@ -444,7 +495,7 @@ cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, ui
 // ---------------------------------------------------------------- launchers
 
 template <int M>
-static hipError_t launch_range_m(const f32x2* in, f32x2* out, uint32_t n_rows, const f32x2* tw, const float* win,
+static hipError_t launch_range_m(const f32x2* in, f32x2* out, uint32_t n_rows, uint32_t nd, const f32x2* tw, const float* win,
                                  hipStream_t s, int device) {
   const uint32_t fpw = frames_per_wg(M);
   const size_t lds = (size_t)8 * fft_image_slots(M) * fpw;
@@ -452,7 +503,7 @@ static hipError_t launch_range_m(const f32x2* in, f32x2* out, uint32_t n_rows, c
   static LdsGrant granted;
   hipError_t e = grant_lds(k, lds, device, granted);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k, dim3((n_rows + fpw - 1) / fpw), dim3(wg_size(M)), lds, s, in, out, n_rows, tw, win);
+  hipLaunchKernelGGL(k, dim3((n_rows + fpw - 1) / fpw), dim3(wg_size(M)), lds, s, in, out, n_rows, nd, tw, win);
   return hipGetLastError();
 }
 
@@ -484,12 +535,12 @@ static hipError_t launch_rd2d_chunk(const Rd2dLaunch& a, uint32_t ch0, uint32_t 
   const float* wd = reinterpret_cast<const float*>(a.win_doppler);
   const uint32_t rows = n_ch * nd;
   switch (a.log2nr) {
-    case 8: e = launch_range_m<8>(in, x1, rows, twr, wr, a.stream, a.device); break;
-    case 9: e = launch_range_m<9>(in, x1, rows, twr, wr, a.stream, a.device); break;
-    case 10: e = launch_range_m<10>(in, x1, rows, twr, wr, a.stream, a.device); break;
-    case 11: e = launch_range_m<11>(in, x1, rows, twr, wr, a.stream, a.device); break;
-    case 12: e = launch_range_m<12>(in, x1, rows, twr, wr, a.stream, a.device); break;
-    case 13: e = launch_range_m<13>(in, x1, rows, twr, wr, a.stream, a.device); break;
+    case 8: e = launch_range_m<8>(in, x1, rows, nd, twr, wr, a.stream, a.device); break;
+    case 9: e = launch_range_m<9>(in, x1, rows, nd, twr, wr, a.stream, a.device); break;
+    case 10: e = launch_range_m<10>(in, x1, rows, nd, twr, wr, a.stream, a.device); break;
+    case 11: e = launch_range_m<11>(in, x1, rows, nd, twr, wr, a.stream, a.device); break;
+    case 12: e = launch_range_m<12>(in, x1, rows, nd, twr, wr, a.stream, a.device); break;
+    case 13: e = launch_range_m<13>(in, x1, rows, nd, twr, wr, a.stream, a.device); break;
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
