@@ -33,28 +33,28 @@ __device__ __forceinline__ float mag2d(f32x2 z, int mode) {
   return __log2f(fmaxf(jpl, FLT_MIN));
 }
 
-// Layout of the two intermediate maps (range spectra, magnitudes) of one channel.  Row-major [d][r] makes the Doppler
-// pass walk the map at a 64-KB pitch at 8192 range bins (HBM rows and channels see a power-of-two stride:
-// 264 us at 8 x 8192 x 1024); tiles of 16 range bins, [r / 16][d][r % 16], give every Doppler workgroup ONE
-// contiguous block (193 us), the range pass still writes whole 128-B lines and the CFAR walker reads 64-B segments of
-// sequential streams.  RSP_RD_TILE=0 builds the row-major layout for A/B runs.
-#ifndef RSP_RD_TILE
-#define RSP_RD_TILE 16
+// Layout of the two intermediate maps (range spectra, magnitudes) of one channel, chosen per launch (rd_tile()):
+// row-major [d][r] up to 4096 range bins; at 8192 the Doppler pass would walk the map at a 64-KiB pitch (HBM banks and
+// channels see one power-of-two stride: 264 us at 8 x 8192 x 1024), so the maps are kept in tiles of 16 range bins,
+// [r / 16][d][r % 16]: every Doppler workgroup reads ONE contiguous block (190 us), the range pass still writes whole
+// 128-B lines (+8 us) and the CFAR walker reads 64-B segments of sequential streams (+5 us).  At 4096 x 512 the tiling
+// costs 4 us more than it saves.  RSP_RD_TILE=0 / 16 force one layout for A/B runs.
+constexpr uint32_t kTileCols = 16;
+__host__ __device__ __forceinline__ size_t map_index(uint32_t d, uint32_t r, uint32_t nd, uint32_t nr, uint32_t tile) {
+  return tile ? ((size_t)(r / kTileCols) * nd + d) * kTileCols + (r % kTileCols) : (size_t)d * nr + r;
+}
+static inline uint32_t rd_tile(int log2nr) {
+#ifdef RSP_RD_TILE
+  return (RSP_RD_TILE) ? kTileCols : 0u;
+#else
+  return log2nr >= 13 ? kTileCols : 0u;
 #endif
-#ifndef RSP_RD_MAGTILE
-#define RSP_RD_MAGTILE RSP_RD_TILE
-#endif
-constexpr uint32_t kMapTile = RSP_RD_TILE, kMagTile = RSP_RD_MAGTILE;  // range spectra, magnitudes
-template <uint32_t TILE>
-__host__ __device__ __forceinline__ size_t map_index(uint32_t d, uint32_t r, uint32_t nd, uint32_t nr) {
-  if constexpr (TILE == 0) return (size_t)d * nr + r;
-  else return ((size_t)(r / TILE) * nd + d) * TILE + (r % TILE);
 }
 
 // ---------------------------------------------------------------- range pass (rows)
 template <int M>
 __global__ void __launch_bounds__(wg_size(M))
-range_fft_kernel(const f32x2* __restrict__ in, f32x2* __restrict__ out, uint32_t n_rows, uint32_t nd,
+range_fft_kernel(const f32x2* __restrict__ in, f32x2* __restrict__ out, uint32_t n_rows, uint32_t nd, uint32_t tile,
                  const f32x2* __restrict__ tw, const float* __restrict__ win) {
   constexpr int N = 1 << M, T = threads_per_frame(M), FPW = frames_per_wg(M);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -76,10 +76,10 @@ range_fft_kernel(const f32x2* __restrict__ in, f32x2* __restrict__ out, uint32_t
   const float scale = 1.0f / (float)N;
   if (!live) return;
   // bins c + tau with c a multiple of T >= 16: the tile index splits into a per-lane and a per-register part
-  static_assert(kMapTile == 0 || T % kMapTile == 0, "a register's bins start on a tile boundary");
+  static_assert(T % kTileCols == 0, "a register's bins start on a tile boundary");
   const uint32_t ch = row / nd, d = row % nd;
-  f32x2* dst = out + (size_t)ch * nd * N + map_index<kMapTile>(d, tau, nd, N);
-  const size_t step = kMapTile ? (size_t)nd : 1;  // elements between bins c and c + 1 tile-columns apart, per bin
+  f32x2* dst = out + (size_t)ch * nd * N + map_index(d, tau, nd, N, tile);
+  const size_t step = tile ? (size_t)nd : 1;  // elements between bins c and c + 1 tile-columns apart, per bin
 #pragma unroll
   for (int g = 0; g < (16 >> WL); ++g) {
 #pragma unroll
@@ -104,24 +104,23 @@ constexpr int kColBytes(int MD) { return 8 * fft_image_slots(MD) + 32; }
 
 template <int MD>
 __global__ void __launch_bounds__(threads_per_frame(MD) * kColsPerWg(MD))
-doppler_mag_kernel(const f32x2* __restrict__ in, float* __restrict__ mag, uint32_t n_ch, uint32_t nr,
+doppler_mag_kernel(const f32x2* __restrict__ in, float* __restrict__ mag, uint32_t n_ch, uint32_t nr, uint32_t tile,
                    int mag_mode, const f32x2* __restrict__ tw, const float* __restrict__ win) {
   constexpr int ND = 1 << MD, T = threads_per_frame(MD), C = kColsPerWg(MD);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // lanes run over the C adjacent range bins first: a wave touches 64 / C rows x (C x 8 B) segments
   const int tid = threadIdx.x, fl = tid % C, tau = tid / C;
-  const uint32_t tiles_per_ch = nr / C;
+  const uint32_t tiles_per_ch = nr / C;  // column groups of C range bins
   // workgroups are dealt round-robin to the 8 XCDs: give each XCD a contiguous run of column tiles, so
   // that the two 8-column tiles sharing a 128-B line meet in the same L2 (-25 % at 1024 Doppler bins;
   // with 16 columns a tile reads whole lines and the plain order is the faster one)
-  const uint32_t tile = ((RSP_DOPPLER_XCDMAP) && gridDim.x % 8 == 0) ? (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8
-                                                            : blockIdx.x;
-  const uint32_t ch = tile / tiles_per_ch, r0 = (tile % tiles_per_ch) * C;
+  const uint32_t wg = ((RSP_DOPPLER_XCDMAP) && gridDim.x % 8 == 0) ? (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8
+                                                                   : blockIdx.x;
+  const uint32_t ch = wg / tiles_per_ch, r0 = (wg % tiles_per_ch) * C;
   f32x2* buf = reinterpret_cast<f32x2*>(smem + (size_t)fl * kColBytes(MD));
   // element index of (ch, d = 0, r) and the distance between Doppler rows, in each of the two maps
-  const size_t col = (size_t)ch * ND * nr + map_index<kMapTile>(0, r0 + fl, ND, nr);
-  const size_t mcol = (size_t)ch * ND * nr + map_index<kMagTile>(0, r0 + fl, ND, nr);
-  const uint32_t pitch = kMapTile ? kMapTile : nr, mpitch = kMagTile ? kMagTile : nr;
+  const size_t col = (size_t)ch * ND * nr + map_index(0, r0 + fl, ND, nr, tile), mcol = col;
+  const uint32_t pitch = tile ? kTileCols : nr, mpitch = pitch;
   const f32x2* src = in + col + (size_t)first_sample<MD>(tau) * pitch;
   f32x2 x[16];
   if (win) {  // slow-time window
@@ -178,7 +177,7 @@ __global__ void __launch_bounds__(256)
 cfar2d_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_t nd, uint32_t nr,
               int ref_r_rt, int guard_r_rt, int ref_d_rt, int guard_d_rt, int edge, float kA, float kB,
               rsp_detection* __restrict__ det_list, uint32_t det_cap, uint32_t* __restrict__ det_counters, uint32_t ch_base,
-              int mode) {
+              int mode, uint32_t tile) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int ref_r = SRR >= 0 ? SRR : ref_r_rt, guard_r = SGR >= 0 ? SGR : guard_r_rt;
   const int ref_d = SRD >= 0 ? SRD : ref_d_rt, guard_d = SGD >= 0 ? SGD : guard_d_rt;
@@ -214,7 +213,7 @@ cfar2d_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_
       for (int u = 0; u < 16; ++u) {
         const int dd = base + 2 * u;
         const int d = (d0 - hd + dd + (int)nd) & ((int)nd - 1);  // Doppler cyclic (nd is a power of two)
-        v[u] = (inside && dd < RH) ? map[map_index<kMagTile>((uint32_t)d, (uint32_t)r, nd, nr)] : 0.f;
+        v[u] = (inside && dd < RH) ? map[map_index((uint32_t)d, (uint32_t)r, nd, nr, tile)] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
@@ -344,6 +343,84 @@ __device__ __forceinline__ float prefix_at(float p0, float p1, int lane) {
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// Row-direction sums of a lane pair's column values v = (column 2l, column 2l + 1), H even:
+//   box = (sum of columns c - H .. c + H) for c = 2l and 2l + 1,  lag = (sum of columns c - H .. c - 1)
+// from runs of 2 and 4 lanes of the pair sums s = v.x + v.y.  Shifts by one lane are DPP wave shifts (VALU), longer
+// ones ds_bpermute (LDS crossbar, no memory): lanes beyond the wave read zero or a wrapped lane, which only reaches
+// lanes outside LB .. LE (they own no output).  Split in two so that the walk can issue the cross-lane reads of one
+// row before it finishes the previous row (walk_issue holds no arithmetic on a ds_bpermute result): a step then
+// never waits for the crossbar round trip it has just started.  (A DPP prefix scan + 8 ds_bpermute taps per step
+// measured 33.5 us at 8 x 4096 x 512; these sums 32.2 us; issued one step ahead: see DESIGN 3.2.)
+struct WalkBox { f32x2 box, lag; };
+__device__ __forceinline__ float lane_up1(float v) { return dpp_f<0x138, 0xf, true>(v); }  // wave_shr:1: lane l - 1
+__device__ __forceinline__ float lane_dn1(float v) { return dpp_f<0x130, 0xf, true>(v); }  // wave_shl:1: lane l + 1
+template <int K>
+__device__ __forceinline__ float lane_at(float v, int lane) {  // value of lane l + K
+  if constexpr (K == 0) return v;
+  else if constexpr (K == -1) return lane_up1(v);
+  else if constexpr (K == 1) return lane_dn1(v);
+  else return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane + K) & 63) << 2, __builtin_bit_cast(int, v)));
+}
+constexpr int lane_runs(int n) { return n <= 0 ? 0 : n / 4 + ((n % 4) >= 2) + (n % 2); }
+// the runs a_k[m] = s[m - 2^k + 1 .. m] (k <= 2) that tile lanes l + FIRST .. l + FIRST + N - 1, longest first, into out[I..]
+template <int FIRST, int N, int I = 0, int NT>
+__device__ __forceinline__ void lane_run_taps(float s, float a1, float a2, int lane, float (&out)[NT]) {
+  if constexpr (N > 0) {
+    constexpr int k = N >= 4 ? 2 : N >= 2 ? 1 : 0, last = FIRST + N - 1;
+    out[I] = lane_at<last>(k == 2 ? a2 : k == 1 ? a1 : s, lane);
+    lane_run_taps<FIRST, N - (1 << k), I + 1>(s, a1, a2, lane, out);
+  }
+}
+template <int H, bool LAG>
+struct WalkTaps {
+  static constexpr int h = H / 2, NC = h == 1 ? 1 : lane_runs(2 * h), NM = (h == 1 || !LAG) ? 1 : lane_runs(h - 1);
+  float core[NC], mid[NM], ym, sm, yp, x;
+};
+template <int H, bool LAG>
+__device__ __forceinline__ WalkTaps<H, LAG> walk_issue(f32x2 v, int lane) {
+  static_assert(H % 2 == 0 && H >= 2 && H <= 30, "even half-width");
+  constexpr int h = H / 2;
+  const float s = v.x + v.y;
+  WalkTaps<H, LAG> t;
+  t.x = v.x;
+  if constexpr (h == 1) {  // one-lane shifts only: no crossbar
+    t.core[0] = s; t.mid[0] = 0.f;
+    t.sm = lane_up1(s); t.ym = lane_up1(v.y); t.yp = lane_dn1(v.x); t.x = lane_dn1(s);
+  } else {
+    // runs of 2 and 4 lanes ending at this lane, built with wave shifts only: every ds_bpermute depends on VALU results alone
+    const float a1 = s + lane_up1(s);
+    const float a2 = a1 + lane_up1(lane_up1(a1));
+    lane_run_taps<-h + 1, 2 * h>(s, a1, a2, lane, t.core);  // lanes l - h + 1 .. l + h (columns 2l - 2h + 2 .. 2l + 2h + 1)
+    if constexpr (LAG) lane_run_taps<-h + 1, h - 1>(s, a1, a2, lane, t.mid);  // lanes l - h + 1 .. l - 1
+    else t.mid[0] = 0.f;
+    t.ym = lane_at<-h>(v.y, lane); t.sm = lane_at<-h>(s, lane); t.yp = lane_at<h>(v.y, lane);
+  }
+  return t;
+}
+template <int H, bool LAG>
+__device__ __forceinline__ WalkBox walk_finish(const WalkTaps<H, LAG>& t, f32x2 v) {
+  constexpr int h = H / 2;
+  WalkBox r;
+  if constexpr (h == 1) {
+    // box(2l) = s[l-1] + s[l] + x[l+1], box(2l+1) = y[l-1] + s[l] + s[l+1]; lag(2l) = s[l-1], lag(2l+1) = y[l-1] + x[l]
+    r.box = f32x2{(t.sm + t.core[0]) + t.yp, (t.ym + t.core[0]) + t.x};
+    r.lag = f32x2{t.sm, t.ym + v.x};
+  } else {
+    float core = t.core[0], mid = t.mid[0];
+#pragma unroll
+    for (int k = 1; k < WalkTaps<H, LAG>::NC; ++k) core += t.core[k];
+#pragma unroll
+    for (int k = 1; k < WalkTaps<H, LAG>::NM; ++k) mid += t.mid[k];
+    r.box = f32x2{(core + t.sm) - t.yp, core + t.ym};
+    // lagging columns: lanes l - h + 1 .. l - 1 whole, plus lane l - h (whole / upper column) and column 2l for c = 2l + 1
+    r.lag = f32x2{mid + t.sm, (mid + t.ym) + v.x};
+  }
+  return r;
+}
+#ifndef RSP_WALK_ALTERNATE
+#define RSP_WALK_ALTERNATE 1
+#endif
 constexpr int kWalkRing = 32;
 constexpr int kWalkStage = 126;  // detections a wave stages in LDS per segment (2 KiB per wave)
 constexpr int walk_lb(int hr) { return (hr + 2) / 2; }
@@ -354,7 +431,8 @@ template <int RR, int GR, int RD, int GD, int SEG, int MODE>
 __global__ void __launch_bounds__(256)
 cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_t nd, uint32_t nr,
                    uint32_t strips, int edge, float kA, float kB,
-                   rsp_detection* __restrict__ det_list, uint32_t det_cap, uint32_t* __restrict__ det_counters, uint32_t ch_base) {
+                   rsp_detection* __restrict__ det_list, uint32_t det_cap, uint32_t* __restrict__ det_counters, uint32_t ch_base,
+                   uint32_t tile) {
   constexpr int HR = RR + GR, HD = RD + GD, SPAN = 2 * HD + 2, RING = kWalkRing;
   constexpr int LB = walk_lb(HR), LE = walk_le(HR), OUTW = walk_outw(HR);
   static_assert(SPAN < RING && SEG % RING == 0, "ring holds the taps plus at least one row in flight");
@@ -376,8 +454,8 @@ cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, ui
       __builtin_amdgcn_make_buffer_rsrc(out + (size_t)ch * nd * nr, 0, (int)map_bytes, (int)kRsrc3);
   const bool readable = edge || (col >= 0 && col < (int)nr);
   const bool owner = lane >= LB && lane <= LE && col < (int)nr;
-  const uint32_t voff_in = readable ? (uint32_t)map_index<kMagTile>(0, (uint32_t)(col & ((int)nr - 1)), nd, nr) * 4u : kOob;
-  const uint32_t row_bytes = (kMagTile ? kMagTile : nr) * 4u;  // address step between Doppler rows of the magnitude map
+  const uint32_t voff_in = readable ? (uint32_t)map_index(0, (uint32_t)(col & ((int)nr - 1)), nd, nr, tile) * 4u : kOob;
+  const uint32_t row_bytes = (tile ? kTileCols : nr) * 4u;  // address step between Doppler rows of the magnitude map
 #ifdef RSP_ABL_WALK_NOSTORE  // ablation builds (tools/ablate_rd.sh): never defined in the product
   const uint32_t voff_out = kOob;
 #else
@@ -385,12 +463,15 @@ cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, ui
 #endif
   const float count = (float)((2 * HR + 1) * (2 * HD + 1) - (2 * GR + 1) * (2 * GD + 1));
   const float kAc = kA / count;
-  // stream row p <-> map row d0 - HD + p (Doppler cyclic)
+  // stream row p <-> map row d0 - HD + p (Doppler cyclic); odd waves walk their segment upwards (row d0 + SEG - 1 +
+  // HD - p): a segment's halo rows are then read at the same time as its neighbour in the workgroup reads them as
+  // its own (both at the start or both at the end of their walks), i.e. once from HBM instead of twice
+  const bool up = RSP_WALK_ALTERNATE && (w & 1);
   auto load_row = [&](int p) -> f32x2 {
 #ifdef RSP_ABL_WALK_ROW0
     const uint32_t d = (uint32_t)(p & 31);
 #else
-    const uint32_t d = (uint32_t)((d0 - HD + p) & ((int)nd - 1));
+    const uint32_t d = (uint32_t)((up ? d0 + SEG - 1 + HD - p : d0 - HD + p) & ((int)nd - 1));
 #endif
     return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_in, voff_in, d * row_bytes, 0));
   };
@@ -409,54 +490,65 @@ cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, ui
   for (int p = 1; p <= 2 * HD; ++p) vo += ring[p];
 #pragma unroll
   for (int p = HD - GD + 1; p <= HD + GD; ++p) vi += ring[p];
-  f32x2 vup = {0.f, 0.f};  // GO / SO: the RD rows above the guard band (the CUT's own column belongs to a half by Doppler side)
+  // GO / SO: the RD rows of the CUT's own column at smaller Doppler than the guard band belong to the lagging half:
+  // the first RD rows of the window when walking down, the last RD when walking up
+  f32x2 vup = {0.f, 0.f};
   if constexpr (MODE != 0) {
+    if (up) {
 #pragma unroll
-    for (int p = 0; p < RD; ++p) vup += ring[p];
+      for (int p = HD + GD + 1; p <= 2 * HD; ++p) vup += ring[p];
+    } else {
+#pragma unroll
+      for (int p = 0; p < RD; ++p) vup += ring[p];
+    }
   }
   const float kAh = 2.0f * kAc;
+  constexpr bool LAG = MODE != 0;
+  // software pipeline, one step deep: the cross-lane reads of row i + 1 are in flight while row i is finished
+  WalkTaps<HR, LAG> to = walk_issue<HR, LAG>(vo, lane);
+  WalkTaps<GR, LAG> ti = walk_issue<GR, LAG>(vi, lane);
+  f32x2 vo_cur = vo, vi_cur = vi, vup_cur = vup;
   for (int chunk = 0; chunk < SEG / RING; ++chunk) {
 #pragma unroll
     for (int u = 0; u < RING; ++u) {
       const int i = chunk * RING + u;
-      ring[(u + RING - 1) % RING] = load_row(i + RING - 1);
-      const float po1 = wave_scan_f(vo.x + vo.y), po0 = po1 - vo.y;
-      const float pi1 = wave_scan_f(vi.x + vi.y), pi0 = pi1 - vi.y;
-      const f32x2 so = {prefix_at<HR>(po0, po1, lane) - prefix_at<-HR - 1>(po0, po1, lane),
-                        prefix_at<1 + HR>(po0, po1, lane) - prefix_at<-HR>(po0, po1, lane)};
-      const f32x2 si = {prefix_at<GR>(pi0, pi1, lane) - prefix_at<-GR - 1>(pi0, pi1, lane),
-                        prefix_at<1 + GR>(pi0, pi1, lane) - prefix_at<-GR>(pi0, pi1, lane)};
+      if (i + RING - 1 < SEG + 2 * HD) ring[(u + RING - 1) % RING] = load_row(i + RING - 1);  // rows past the walk's last window are not read
       const f32x2 cut = ring[(u + HD) % RING];
+      // column sums of row i + 1 and its cross-lane reads (the last step's are never used)
+      vo += ring[(u + SPAN - 1) % RING] - ring[u];
+      vi += ring[(u + HD + GD + 1) % RING] - ring[(u + HD - GD) % RING];
+      if constexpr (LAG) vup += up ? ring[(u + SPAN - 1) % RING] - ring[(u + HD + GD + 1) % RING] : ring[(u + RD) % RING] - ring[u];
+      const WalkTaps<HR, LAG> to_next = walk_issue<HR, LAG>(vo, lane);
+      const WalkTaps<GR, LAG> ti_next = walk_issue<GR, LAG>(vi, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      const WalkBox bo = walk_finish<HR, LAG>(to, vo_cur), bi = walk_finish<GR, LAG>(ti, vi_cur);
       float t0, t1;
       if constexpr (MODE == 0) {
-        t0 = __fmaf_rn(so.x - si.x, kAc, kB);
-        t1 = __fmaf_rn(so.y - si.y, kAc, kB);
+        t0 = __fmaf_rn(bo.box.x - bi.box.x, kAc, kB);
+        t1 = __fmaf_rn(bo.box.y - bi.box.y, kAc, kB);
       } else {
-        // lagging half: columns c - H .. c - 1 of the box sums (the prefix at c - 1 is this lane's own) + the rows of
-        // column c above the guard; leading half = the rest of the training region
-        const f32x2 lago = {(po0 - vo.x) - prefix_at<-HR - 1>(po0, po1, lane), po0 - prefix_at<-HR>(po0, po1, lane)};
-        const f32x2 lagi = {(pi0 - vi.x) - prefix_at<-GR - 1>(pi0, pi1, lane), pi0 - prefix_at<-GR>(pi0, pi1, lane)};
-        const f32x2 lag = (lago - lagi) + vup, lead = (so - si) - lag;
+        // lagging half: columns c - H .. c - 1 of the box sums + the rows of column c above the guard; leading half =
+        // the rest of the training region
+        const f32x2 lag = (bo.lag - bi.lag) + vup_cur, lead = (bo.box - bi.box) - lag;
         t0 = __fmaf_rn(MODE == 1 ? fmaxf(lag.x, lead.x) : fminf(lag.x, lead.x), kAh, kB);
         t1 = __fmaf_rn(MODE == 1 ? fmaxf(lag.y, lead.y) : fminf(lag.y, lead.y), kAh, kB);
       }
       u32x2 wd;
       wd.x = (__float_as_uint(t0) & ~1u) | (uint32_t)(cut.x > t0);
       wd.y = (__float_as_uint(t1) & ~1u) | (uint32_t)(cut.y > t1);
-      __builtin_amdgcn_raw_buffer_store_b64(wd, rsrc_out, voff_out, (uint32_t)(d0 + i) * nr * 4u, 0);
+      const uint32_t d_out = (uint32_t)(up ? d0 + SEG - 1 - i : d0 + i);
+      __builtin_amdgcn_raw_buffer_store_b64(wd, rsrc_out, voff_out, d_out * nr * 4u, 0);
       if ((wd.x | wd.y) & det_mask) {  // rare
         if (wd.x & 1u) {
           const uint32_t sl = atomicAdd(&stage_cnt[w], 1u);
-          if (sl < (uint32_t)kWalkStage) stage[w][sl] = u32x4{ch_base + ch, (uint32_t)col, (uint32_t)(d0 + i), wd.x};
+          if (sl < (uint32_t)kWalkStage) stage[w][sl] = u32x4{ch_base + ch, (uint32_t)col, d_out, wd.x};
         }
         if (wd.y & 1u) {
           const uint32_t sl = atomicAdd(&stage_cnt[w], 1u);
-          if (sl < (uint32_t)kWalkStage) stage[w][sl] = u32x4{ch_base + ch, (uint32_t)col + 1u, (uint32_t)(d0 + i), wd.y};
+          if (sl < (uint32_t)kWalkStage) stage[w][sl] = u32x4{ch_base + ch, (uint32_t)col + 1u, d_out, wd.y};
         }
       }
-      vo += ring[(u + SPAN - 1) % RING] - ring[u];
-      vi += ring[(u + HD + GD + 1) % RING] - ring[(u + HD - GD) % RING];
-      if constexpr (MODE != 0) vup += ring[(u + RD) % RING] - ring[u];
+      to = to_next; ti = ti_next; vo_cur = vo; vi_cur = vi; vup_cur = vup;
       // keep every row's load at the top of its own step: the scheduler would otherwise sink the
       // loads next to their first use, 10 rows later, and drain the prefetch pipeline
       __builtin_amdgcn_sched_barrier(0);
@@ -495,7 +587,7 @@ cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, ui
 // ---------------------------------------------------------------- launchers
 
 template <int M>
-static hipError_t launch_range_m(const f32x2* in, f32x2* out, uint32_t n_rows, uint32_t nd, const f32x2* tw, const float* win,
+static hipError_t launch_range_m(const f32x2* in, f32x2* out, uint32_t n_rows, uint32_t nd, uint32_t tile, const f32x2* tw, const float* win,
                                  hipStream_t s, int device) {
   const uint32_t fpw = frames_per_wg(M);
   const size_t lds = (size_t)8 * fft_image_slots(M) * fpw;
@@ -503,12 +595,12 @@ static hipError_t launch_range_m(const f32x2* in, f32x2* out, uint32_t n_rows, u
   static LdsGrant granted;
   hipError_t e = grant_lds(k, lds, device, granted);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k, dim3((n_rows + fpw - 1) / fpw), dim3(wg_size(M)), lds, s, in, out, n_rows, nd, tw, win);
+  hipLaunchKernelGGL(k, dim3((n_rows + fpw - 1) / fpw), dim3(wg_size(M)), lds, s, in, out, n_rows, nd, tile, tw, win);
   return hipGetLastError();
 }
 
 template <int MD>
-static hipError_t launch_doppler_m(const f32x2* in, float* mag, uint32_t n_ch, uint32_t nr, int mode,
+static hipError_t launch_doppler_m(const f32x2* in, float* mag, uint32_t n_ch, uint32_t nr, uint32_t tile, int mode,
                                    const f32x2* tw, const float* win, hipStream_t s, int device) {
   constexpr int C = kColsPerWg(MD);
   const size_t lds = (size_t)kColBytes(MD) * C;
@@ -517,7 +609,7 @@ static hipError_t launch_doppler_m(const f32x2* in, float* mag, uint32_t n_ch, u
   hipError_t e = grant_lds(k, lds, device, granted);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3(n_ch * (nr / C)), dim3(threads_per_frame(MD) * C), lds, s, in, mag, n_ch,
-                     nr, mode, tw, win);
+                     nr, tile, mode, tw, win);
   return hipGetLastError();
 }
 
@@ -533,21 +625,21 @@ static hipError_t launch_rd2d_chunk(const Rd2dLaunch& a, uint32_t ch0, uint32_t 
   const f32x2* twd = reinterpret_cast<const f32x2*>(a.tw_doppler);
   const float* wr = reinterpret_cast<const float*>(a.regs.window);
   const float* wd = reinterpret_cast<const float*>(a.win_doppler);
-  const uint32_t rows = n_ch * nd;
+  const uint32_t rows = n_ch * nd, tile = rd_tile(a.log2nr);
   switch (a.log2nr) {
-    case 8: e = launch_range_m<8>(in, x1, rows, nd, twr, wr, a.stream, a.device); break;
-    case 9: e = launch_range_m<9>(in, x1, rows, nd, twr, wr, a.stream, a.device); break;
-    case 10: e = launch_range_m<10>(in, x1, rows, nd, twr, wr, a.stream, a.device); break;
-    case 11: e = launch_range_m<11>(in, x1, rows, nd, twr, wr, a.stream, a.device); break;
-    case 12: e = launch_range_m<12>(in, x1, rows, nd, twr, wr, a.stream, a.device); break;
-    case 13: e = launch_range_m<13>(in, x1, rows, nd, twr, wr, a.stream, a.device); break;
+    case 8: e = launch_range_m<8>(in, x1, rows, nd, tile, twr, wr, a.stream, a.device); break;
+    case 9: e = launch_range_m<9>(in, x1, rows, nd, tile, twr, wr, a.stream, a.device); break;
+    case 10: e = launch_range_m<10>(in, x1, rows, nd, tile, twr, wr, a.stream, a.device); break;
+    case 11: e = launch_range_m<11>(in, x1, rows, nd, tile, twr, wr, a.stream, a.device); break;
+    case 12: e = launch_range_m<12>(in, x1, rows, nd, tile, twr, wr, a.stream, a.device); break;
+    case 13: e = launch_range_m<13>(in, x1, rows, nd, tile, twr, wr, a.stream, a.device); break;
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
   switch (a.log2nd) {
-    case 8: e = launch_doppler_m<8>(x1, a.scratch_mag, n_ch, nr, a.regs.mag_mode, twd, wd, a.stream, a.device); break;
-    case 9: e = launch_doppler_m<9>(x1, a.scratch_mag, n_ch, nr, a.regs.mag_mode, twd, wd, a.stream, a.device); break;
-    case 10: e = launch_doppler_m<10>(x1, a.scratch_mag, n_ch, nr, a.regs.mag_mode, twd, wd, a.stream, a.device); break;
+    case 8: e = launch_doppler_m<8>(x1, a.scratch_mag, n_ch, nr, tile, a.regs.mag_mode, twd, wd, a.stream, a.device); break;
+    case 9: e = launch_doppler_m<9>(x1, a.scratch_mag, n_ch, nr, tile, a.regs.mag_mode, twd, wd, a.stream, a.device); break;
+    case 10: e = launch_doppler_m<10>(x1, a.scratch_mag, n_ch, nr, tile, a.regs.mag_mode, twd, wd, a.stream, a.device); break;
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
@@ -567,7 +659,7 @@ static hipError_t launch_rd2d_chunk(const Rd2dLaunch& a, uint32_t ch0, uint32_t 
     const dim3 grid(n_ch * strips * (nd / SEG / 4));
 #define RSP_WALK(MODE)                                                                                              \
   hipLaunchKernelGGL((cfar2d_walk_kernel<8, 2, 8, 2, SEG, MODE>), grid, dim3(256), 0, a.stream, a.scratch_mag, out, \
-                     nd, nr, strips, a.regs.edge, kA, kB, a.det_list, a.det_cap, a.det_counters, ch0)
+                     nd, nr, strips, a.regs.edge, kA, kB, a.det_list, a.det_cap, a.det_counters, ch0, tile)
     if (a.regs.cfar_mode == 0) RSP_WALK(0);
     else if (a.regs.cfar_mode == 1) RSP_WALK(1);
     else RSP_WALK(2);
@@ -580,7 +672,7 @@ static hipError_t launch_rd2d_chunk(const Rd2dLaunch& a, uint32_t ch0, uint32_t 
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3(n_ch * (nr / kTR) * (nd / kTD)), dim3(256), lds, a.stream, a.scratch_mag, out,
                      nd, nr, a.regs.R, a.regs.G, a.ref_d, a.guard_d, a.regs.edge, kA, kB, a.det_list, a.det_cap,
-                     a.det_counters, ch0, a.regs.cfar_mode);
+                     a.det_counters, ch0, a.regs.cfar_mode, tile);
   return hipGetLastError();
 }
 
