@@ -1416,15 +1416,21 @@ __device__ __forceinline__ uint32_t reserve_block(uint32_t* counters, uint32_t f
   return base;
 }
 
-// Per-frame slots written by chain1d_kernel -> one compact list.  One thread per
-// frame, 256 frames per workgroup, ONE global atomic per counter per workgroup (a block of
-// the list is reserved from the scanned per-frame counts).
+// Per-frame slots written by the chain kernels -> one compact list, frames in ascending order.  One thread per frame,
+// 256 frames per workgroup.  PREFIX = true (up to kPrefixFrames frames): every workgroup sums the counts of ALL
+// frames before its own (a few KiB of L2 reads, all in flight together) instead of reserving its block of the list with
+// device-scope atomics -- no counters, no ticket, a deterministic list, and three atomic round trips (~2.5 us of an
+// 8 us launch) off the critical path; the last workgroup publishes {found, stored}.  PREFIX = false: a block of the
+// list is reserved with one returning atomic per workgroup (blocks land in completion order).
+constexpr uint32_t kPrefixFrames = 16384;
+
+template <bool PREFIX>
 __global__ void __launch_bounds__(256)
 compact_frames_kernel(const uint32_t* __restrict__ fcount, const uint2* __restrict__ fdet,
                       uint32_t n_frames, const uint32_t* __restrict__ words, int log2n, int word_shift,
                       rsp_detection* __restrict__ list, uint32_t cap,
                       uint32_t* __restrict__ counters, uint32_t* __restrict__ d_count) {
-  __shared__ uint32_t wave_tot[4], wave_found[4];
+  __shared__ uint32_t wave_tot[4], wave_found[4], wave_pre[4], wave_pref[4];
   __shared__ uint32_t base_sh, ovf_n, ovf_cursor;
   __shared__ uint32_t ovf_frame[256], ovf_base[256];
   const uint32_t f = blockIdx.x * 256 + threadIdx.x;
@@ -1434,6 +1440,17 @@ compact_frames_kernel(const uint32_t* __restrict__ fcount, const uint2* __restri
   const uint32_t mine = (ovf && !words) ? (uint32_t)kFrameDetCap : found;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) ovf_n = 0u;
+  uint32_t pre = 0, pre_found = 0;  // entries / peaks of the frames before this workgroup's (partial sums per thread)
+  if constexpr (PREFIX) {
+    const uint32_t before = blockIdx.x * 256u;  // a multiple of 4, all of them < n_frames
+    const u32x4* fc4 = reinterpret_cast<const u32x4*>(fcount);
+    for (uint32_t i = threadIdx.x; i < before / 4; i += 256) {
+      const u32x4 c = fc4[i];
+      pre_found += (c.x + c.y) + (c.z + c.w);
+      if (words) pre += (c.x + c.y) + (c.z + c.w);
+      else pre += min(c.x, (uint32_t)kFrameDetCap) + min(c.y, (uint32_t)kFrameDetCap) + min(c.z, (uint32_t)kFrameDetCap) + min(c.w, (uint32_t)kFrameDetCap);
+    }
+  }
   uint32_t inc = mine, tot_found = found;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -1441,33 +1458,59 @@ compact_frames_kernel(const uint32_t* __restrict__ fcount, const uint2* __restri
     if (lane >= d) inc += t;
   }
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) tot_found += __shfl_xor(tot_found, d);
+  for (int d = 32; d >= 1; d >>= 1) {
+    tot_found += __shfl_xor(tot_found, d);
+    if constexpr (PREFIX) {
+      pre += __shfl_xor(pre, d);
+      pre_found += __shfl_xor(pre_found, d);
+    }
+  }
   if (lane == 63) wave_tot[wave] = inc;
-  if (lane == 0) wave_found[wave] = tot_found;
+  if (lane == 0) {
+    wave_found[wave] = tot_found;
+    wave_pre[wave] = pre;
+    wave_pref[wave] = pre_found;
+  }
   __syncthreads();
   uint32_t off = inc - mine;
   for (int w = 0; w < wave; ++w) off += wave_tot[w];
-  if (threadIdx.x == 0) {
-    const uint32_t tot = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-    const uint32_t fnd = wave_found[0] + wave_found[1] + wave_found[2] + wave_found[3];
-    base_sh = reserve_block(counters, fnd, tot);
+  const uint32_t tot = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+  const uint32_t fnd = wave_found[0] + wave_found[1] + wave_found[2] + wave_found[3];
+  uint32_t base;
+  if constexpr (PREFIX) {
+    const uint32_t wg_base = wave_pre[0] + wave_pre[1] + wave_pre[2] + wave_pre[3];
+    base = wg_base + off;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+      const uint32_t cursor = wg_base + tot;
+      d_count[0] = wave_pref[0] + wave_pref[1] + wave_pref[2] + wave_pref[3] + fnd;
+      d_count[1] = cursor < cap ? cursor : cap;
+    }
+  } else {
+    if (threadIdx.x == 0) base_sh = reserve_block(counters, fnd, tot);
+    __syncthreads();
+    base = base_sh + off;
   }
-  __syncthreads();
-  const uint32_t base = base_sh + off;
   if (ovf && words) {
     const uint32_t s = atomicAdd(&ovf_n, 1u);
     ovf_frame[s] = f;
     ovf_base[s] = base;
   } else {
-    for (uint32_t i = 0; i < mine; ++i) {
-      if (base + i >= cap) break;
-      const uint2 e = fdet[(size_t)f * kFrameDetCap + i];
-      rsp_detection d;
-      d.frame = f;
-      d.bin = e.x;
-      d.doppler = 0;
-      d.word = e.y;
-      list[base + i] = d;
+    // four slots (two 16-byte loads) per round: the rounds' loads do not wait for each other's stores
+    const u32x4* src = reinterpret_cast<const u32x4*>(fdet + (size_t)f * kFrameDetCap);
+    for (uint32_t i = 0; i < mine; i += 4) {
+      const u32x4 e01 = src[i / 2], e23 = (i + 2 < mine) ? src[i / 2 + 1] : u32x4{0u, 0u, 0u, 0u};
+      const uint32_t bins[4] = {e01.x, e01.z, e23.x, e23.z}, wds[4] = {e01.y, e01.w, e23.y, e23.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (i + q < mine && base + i + q < cap) {
+          rsp_detection d;
+          d.frame = f;
+          d.bin = bins[q];
+          d.doppler = 0;
+          d.word = wds[q];
+          list[base + i + q] = d;
+        }
+      }
     }
   }
   __syncthreads();
@@ -1494,15 +1537,19 @@ compact_frames_kernel(const uint32_t* __restrict__ fcount, const uint2* __restri
     }
     __syncthreads();
   }
-  publish_counts(counters, cap, d_count);
+  if constexpr (!PREFIX) publish_counts(counters, cap, d_count);
 }
 
 hipError_t launch_compact_frames(const uint32_t* fcount, const uint2* fdet, uint32_t n_frames,
                                  const uint32_t* words, int log2n, int word_shift, rsp_detection* list,
                                  uint32_t cap, uint32_t* counters, uint32_t* d_count, hipStream_t stream) {
   if (n_frames == 0) return hipMemsetAsync(d_count, 0, 2 * sizeof(uint32_t), stream);
-  hipLaunchKernelGGL(compact_frames_kernel, dim3((n_frames + 255) / 256), dim3(256), 0, stream,
-                     fcount, fdet, n_frames, words, log2n, word_shift, list, cap, counters, d_count);
+  if (n_frames <= kPrefixFrames)
+    hipLaunchKernelGGL(compact_frames_kernel<true>, dim3((n_frames + 255) / 256), dim3(256), 0, stream,
+                       fcount, fdet, n_frames, words, log2n, word_shift, list, cap, counters, d_count);
+  else
+    hipLaunchKernelGGL(compact_frames_kernel<false>, dim3((n_frames + 255) / 256), dim3(256), 0, stream,
+                       fcount, fdet, n_frames, words, log2n, word_shift, list, cap, counters, d_count);
   return hipGetLastError();
 }
 

@@ -53,8 +53,7 @@ struct Rd2dLaunch {
   // atomic per PEAK, none otherwise), so no second pass over the dense words is needed
   rsp_detection* det_list;  // device, or NULL
   uint32_t det_cap;
-  uint32_t* det_counters;   // kCompactCounters words, zero on entry; [0] = [1] = peaks appended so far
-  uint32_t* det_count;      // device uint32[2]: {found, stored}, written by the finalize launch
+  uint32_t* det_count;      // device uint32[2]: {found, stored}: zeroed by the range pass, advanced by the CFAR kernels
 };
 hipError_t launch_rd2d(const Rd2dLaunch& a);
 // channels per chunk (>= 1) and the scratch the API has to provide for it

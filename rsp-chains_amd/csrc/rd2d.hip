@@ -55,12 +55,13 @@ static inline uint32_t rd_tile(int log2nr) {
 template <int M>
 __global__ void __launch_bounds__(wg_size(M))
 range_fft_kernel(const f32x2* __restrict__ in, f32x2* __restrict__ out, uint32_t n_rows, uint32_t nd, uint32_t tile,
-                 const f32x2* __restrict__ tw, const float* __restrict__ win) {
+                 const f32x2* __restrict__ tw, const float* __restrict__ win, uint32_t* __restrict__ zero_count) {
   constexpr int N = 1 << M, T = threads_per_frame(M), FPW = frames_per_wg(M);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, fl = tid / T, tau = tid % T;
   const uint32_t row = blockIdx.x * FPW + fl;
   const bool live = row < n_rows;
+  if (zero_count && blockIdx.x == 0 && tid == 0) zero_count[0] = zero_count[1] = 0u;  // the detection list's {found, stored}
   f32x2* buf = reinterpret_cast<f32x2*>(smem) + (size_t)fl * fft_image_slots(M);
   const f32x2* src = in + (size_t)(live ? row : 0) * N + first_sample<M>(tau);
   f32x2 x[16];
@@ -149,12 +150,18 @@ doppler_mag_kernel(const f32x2* __restrict__ in, float* __restrict__ mag, uint32
 }
 
 // ---------------------------------------------------------------- fused detection list
-// A peak cell appends itself: ONE device-scope atomic per peak (peaks are ~1e-5 of the cells), none
-// otherwise.  counters[0] counts the peaks (zero on entry, re-zeroed by the finalize launch, which also
-// publishes stored = min(found, cap)).
-__device__ __forceinline__ void append_peak(rsp_detection* __restrict__ list, uint32_t cap, uint32_t* __restrict__ counters,
+// d_count = {found, stored} is the list's own cursor: the range pass (first launch of the batch) zeroes it, a wave /
+// cell that found peaks reserves its entries with ONE returning device-scope atomic on found and folds
+// min(found so far, cap) into stored with an atomic max (the maximum over all reservations is min(total, cap)).
+// No counters to clean, no finalize launch (4.8 us per batch as its own kernel).  Peaks are ~1e-5 of the cells.
+__device__ __forceinline__ uint32_t reserve_peaks(uint32_t* __restrict__ d_count, uint32_t cap, uint32_t n) {
+  const uint32_t base = atomicAdd(&d_count[0], n);
+  atomicMax(&d_count[1], base + n < cap ? base + n : cap);
+  return base;
+}
+__device__ __forceinline__ void append_peak(rsp_detection* __restrict__ list, uint32_t cap, uint32_t* __restrict__ d_count,
                                             uint32_t ch, uint32_t doppler, uint32_t range, uint32_t word) {
-  const uint32_t slot = atomicAdd(&counters[0], 1u);  // found; the finalize launch sets stored = min(found, cap)
+  const uint32_t slot = reserve_peaks(d_count, cap, 1u);
   if (slot < cap) {
     rsp_detection d;
     d.frame = ch;
@@ -176,7 +183,7 @@ template <int SRR, int SGR, int SRD, int SGD>
 __global__ void __launch_bounds__(256)
 cfar2d_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_t nd, uint32_t nr,
               int ref_r_rt, int guard_r_rt, int ref_d_rt, int guard_d_rt, int edge, float kA, float kB,
-              rsp_detection* __restrict__ det_list, uint32_t det_cap, uint32_t* __restrict__ det_counters, uint32_t ch_base,
+              rsp_detection* __restrict__ det_list, uint32_t det_cap, uint32_t* __restrict__ det_count, uint32_t ch_base,
               int mode, uint32_t tile) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int ref_r = SRR >= 0 ? SRR : ref_r_rt, guard_r = SGR >= 0 ? SGR : guard_r_rt;
@@ -303,7 +310,7 @@ cfar2d_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_
       const float cut = m[(dseg + j + hd) * MS + c + hr];
       const uint32_t wd = (__float_as_uint(thr) & ~1u) | (uint32_t)(cut > thr);
       dst[(size_t)j * nr] = wd;
-      if (det_list && (wd & 1u)) append_peak(det_list, det_cap, det_counters, ch_base + ch, (uint32_t)(d0 + dseg + j), (uint32_t)(r0 + c), wd);
+      if (det_list && (wd & 1u)) append_peak(det_list, det_cap, det_count, ch_base + ch, (uint32_t)(d0 + dseg + j), (uint32_t)(r0 + c), wd);
       so += co[(j + hd + 1) * (kTR + 1)] - co[(j - hd) * (kTR + 1)];
       si += ci[(j + guard_d + 1) * (kTR + 1)] - ci[(j - guard_d) * (kTR + 1)];
     }
@@ -431,7 +438,7 @@ template <int RR, int GR, int RD, int GD, int SEG, int MODE>
 __global__ void __launch_bounds__(256)
 cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_t nd, uint32_t nr,
                    uint32_t strips, int edge, float kA, float kB,
-                   rsp_detection* __restrict__ det_list, uint32_t det_cap, uint32_t* __restrict__ det_counters, uint32_t ch_base,
+                   rsp_detection* __restrict__ det_list, uint32_t det_cap, uint32_t* __restrict__ det_count, uint32_t ch_base,
                    uint32_t tile) {
   constexpr int HR = RR + GR, HD = RD + GD, SPAN = 2 * HD + 2, RING = kWalkRing;
   constexpr int LB = walk_lb(HR), LE = walk_le(HR), OUTW = walk_outw(HR);
@@ -558,7 +565,7 @@ cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, ui
     const uint32_t n = stage_cnt[w];  // wave-private: this wave's LDS operations execute in order
     if (n > 0u && n <= (uint32_t)kWalkStage) {
       uint32_t base = 0u;
-      if (lane == 0) base = atomicAdd(&det_counters[0], n);  // ONE device-scope atomic per wave that found something
+      if (lane == 0) base = reserve_peaks(det_count, det_cap, n);  // once per wave that found something
       base = __builtin_amdgcn_readfirstlane(base);
       for (uint32_t k = lane; k < n; k += 64) {
         if (base + k < det_cap) {
@@ -577,8 +584,8 @@ cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, ui
 #pragma unroll 1
       for (int i = 0; i < SEG; ++i) {
         const u32x2 wd = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_out, voff_out, (uint32_t)(d0 + i) * nr * 4u, 1 /* glc */));
-        if (wd.x & 1u) append_peak(det_list, det_cap, det_counters, ch_base + ch, (uint32_t)(d0 + i), (uint32_t)col, wd.x);
-        if (wd.y & 1u) append_peak(det_list, det_cap, det_counters, ch_base + ch, (uint32_t)(d0 + i), (uint32_t)col + 1u, wd.y);
+        if (wd.x & 1u) append_peak(det_list, det_cap, det_count, ch_base + ch, (uint32_t)(d0 + i), (uint32_t)col, wd.x);
+        if (wd.y & 1u) append_peak(det_list, det_cap, det_count, ch_base + ch, (uint32_t)(d0 + i), (uint32_t)col + 1u, wd.y);
       }
     }
   }
@@ -587,7 +594,7 @@ cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, ui
 // ---------------------------------------------------------------- launchers
 
 template <int M>
-static hipError_t launch_range_m(const f32x2* in, f32x2* out, uint32_t n_rows, uint32_t nd, uint32_t tile, const f32x2* tw, const float* win,
+static hipError_t launch_range_m(const f32x2* in, f32x2* out, uint32_t n_rows, uint32_t nd, uint32_t tile, const f32x2* tw, const float* win, uint32_t* zero_count,
                                  hipStream_t s, int device) {
   const uint32_t fpw = frames_per_wg(M);
   const size_t lds = (size_t)8 * fft_image_slots(M) * fpw;
@@ -595,7 +602,7 @@ static hipError_t launch_range_m(const f32x2* in, f32x2* out, uint32_t n_rows, u
   static LdsGrant granted;
   hipError_t e = grant_lds(k, lds, device, granted);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k, dim3((n_rows + fpw - 1) / fpw), dim3(wg_size(M)), lds, s, in, out, n_rows, nd, tile, tw, win);
+  hipLaunchKernelGGL(k, dim3((n_rows + fpw - 1) / fpw), dim3(wg_size(M)), lds, s, in, out, n_rows, nd, tile, tw, win, zero_count);
   return hipGetLastError();
 }
 
@@ -626,13 +633,14 @@ static hipError_t launch_rd2d_chunk(const Rd2dLaunch& a, uint32_t ch0, uint32_t 
   const float* wr = reinterpret_cast<const float*>(a.regs.window);
   const float* wd = reinterpret_cast<const float*>(a.win_doppler);
   const uint32_t rows = n_ch * nd, tile = rd_tile(a.log2nr);
+  uint32_t* zero_count = (a.det_list && ch0 == 0) ? a.det_count : nullptr;  // first chunk of the batch
   switch (a.log2nr) {
-    case 8: e = launch_range_m<8>(in, x1, rows, nd, tile, twr, wr, a.stream, a.device); break;
-    case 9: e = launch_range_m<9>(in, x1, rows, nd, tile, twr, wr, a.stream, a.device); break;
-    case 10: e = launch_range_m<10>(in, x1, rows, nd, tile, twr, wr, a.stream, a.device); break;
-    case 11: e = launch_range_m<11>(in, x1, rows, nd, tile, twr, wr, a.stream, a.device); break;
-    case 12: e = launch_range_m<12>(in, x1, rows, nd, tile, twr, wr, a.stream, a.device); break;
-    case 13: e = launch_range_m<13>(in, x1, rows, nd, tile, twr, wr, a.stream, a.device); break;
+    case 8: e = launch_range_m<8>(in, x1, rows, nd, tile, twr, wr, zero_count, a.stream, a.device); break;
+    case 9: e = launch_range_m<9>(in, x1, rows, nd, tile, twr, wr, zero_count, a.stream, a.device); break;
+    case 10: e = launch_range_m<10>(in, x1, rows, nd, tile, twr, wr, zero_count, a.stream, a.device); break;
+    case 11: e = launch_range_m<11>(in, x1, rows, nd, tile, twr, wr, zero_count, a.stream, a.device); break;
+    case 12: e = launch_range_m<12>(in, x1, rows, nd, tile, twr, wr, zero_count, a.stream, a.device); break;
+    case 13: e = launch_range_m<13>(in, x1, rows, nd, tile, twr, wr, zero_count, a.stream, a.device); break;
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
@@ -659,7 +667,7 @@ static hipError_t launch_rd2d_chunk(const Rd2dLaunch& a, uint32_t ch0, uint32_t 
     const dim3 grid(n_ch * strips * (nd / SEG / 4));
 #define RSP_WALK(MODE)                                                                                              \
   hipLaunchKernelGGL((cfar2d_walk_kernel<8, 2, 8, 2, SEG, MODE>), grid, dim3(256), 0, a.stream, a.scratch_mag, out, \
-                     nd, nr, strips, a.regs.edge, kA, kB, a.det_list, a.det_cap, a.det_counters, ch0, tile)
+                     nd, nr, strips, a.regs.edge, kA, kB, a.det_list, a.det_cap, a.det_count, ch0, tile)
     if (a.regs.cfar_mode == 0) RSP_WALK(0);
     else if (a.regs.cfar_mode == 1) RSP_WALK(1);
     else RSP_WALK(2);
@@ -672,7 +680,7 @@ static hipError_t launch_rd2d_chunk(const Rd2dLaunch& a, uint32_t ch0, uint32_t 
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3(n_ch * (nr / kTR) * (nd / kTD)), dim3(256), lds, a.stream, a.scratch_mag, out,
                      nd, nr, a.regs.R, a.regs.G, a.ref_d, a.guard_d, a.regs.edge, kA, kB, a.det_list, a.det_cap,
-                     a.det_counters, ch0, a.regs.cfar_mode, tile);
+                     a.det_count, ch0, a.regs.cfar_mode, tile);
   return hipGetLastError();
 }
 
@@ -680,13 +688,12 @@ static hipError_t launch_rd2d_chunk(const Rd2dLaunch& a, uint32_t ch0, uint32_t 
 // 4 B/cell) fit the 256 MiB Infinity Cache together with the streams passing by, and every chunk reuses the SAME
 // scratch memory, so the corner turn and the magnitude map are re-read from cache instead of HBM.
 hipError_t launch_rd2d(const Rd2dLaunch& a) {
-  if (a.n_ch == 0) return hipSuccess;
+  if (a.n_ch == 0) return a.det_list ? hipMemsetAsync(a.det_count, 0, 2 * sizeof(uint32_t), a.stream) : hipSuccess;
   const uint32_t per = rd2d_chunk_channels(a.log2nr, a.log2nd, a.n_ch, a.chunk_bytes);
   for (uint32_t c0 = 0; c0 < a.n_ch; c0 += per) {
     hipError_t e = launch_rd2d_chunk(a, c0, a.n_ch - c0 < per ? a.n_ch - c0 : per);
     if (e != hipSuccess) return e;
   }
-  if (a.det_list) return launch_compact_finalize(a.det_counters, a.det_cap, a.det_count, true, a.stream);
   return hipSuccess;
 }
 

@@ -524,7 +524,6 @@ int launch_rd(rsp_chain* c, const void* d_in, size_t n_ch, uint32_t* d_out, rsp_
   if (d_found) {
     a.det_list = d_list;
     a.det_cap = cap;
-    a.det_counters = c->d_ctr;
     a.det_count = d_found;
   }
   hipEvent_t pe1 = nullptr;
