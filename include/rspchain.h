@@ -133,7 +133,7 @@ typedef struct rsp_chain_params {
   /* ---- extensions with no reference counterpart ---- */
   int32_t dtype;     /* RSP_DTYPE_* */
   int32_t device;    /* HIP device ordinal */
-  int32_t dopplerPoints; /* 0 = 1-D chain; else slow-time FFT size of the 2-D range-Doppler chain */
+  int32_t dopplerPoints; /* 0 = 1-D chain; else slow-time FFT size of the 2-D range-Doppler chain (either dtype) */
   int32_t refDoppler;    /* 2-D CFAR training / guard half-widths along Doppler */
   int32_t guardDoppler;
   int32_t window;        /* RSP_WINDOW_*: pre-FFT window over fast time (range); SURVEY 8f-n4, no reference item */

@@ -99,6 +99,8 @@ def lib():
                                       C.c_void_p, C.c_void_p, C.c_int]
         L.orc_rd_f32in.argtypes = [C.c_void_p, C.c_size_t, P(OrcRdCfg), C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_rd_fixed.argtypes = [C.c_void_p, C.c_size_t, P(OrcCfg), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                   C.c_void_p, C.c_int]
         L.orc_plfg.argtypes = [P(OrcStimCfg), C.c_size_t, C.c_void_p]
         L.orc_plfg_nco.argtypes = [P(OrcStimCfg), C.c_size_t, C.c_void_p]
         _lib = L
@@ -237,6 +239,20 @@ def rd_f32(x, cfg: OrcRdCfg, n_threads: int = 1, want_mag: bool = False):
     lib().orc_rd_f32in(_p(x), ch, C.byref(cfg), _p(thr), _p(peak), _p(margin),
                        _p(mag) if want_mag else None, n_threads)
     return (thr, peak, margin, mag) if want_mag else (thr, peak, margin)
+
+
+def rd_fixed(in_beats, cfg: OrcCfg, log2nd: int, ref_d: int, guard_d: int, window_d: int = 0, n_threads: int = 1,
+             want_mag: bool = False):
+    """2-D chain, FIXED16: in_beats uint32 [n_ch, n_doppler, n_range] packed IQ; cfg = the 1-D register file with
+    log2n = log2(n_range), ref_window / guard_window = range half-widths.  Returns words [n_ch, nd, nr] (, magnitudes)."""
+    nr, nd = 1 << cfg.log2n, 1 << log2nd
+    beats = np.ascontiguousarray(in_beats, np.uint32).reshape(-1, nd, nr)
+    ch = beats.shape[0]
+    out = np.zeros((ch, nd, nr), np.uint32)
+    mag = np.zeros((ch, nd, nr), np.int32) if want_mag else None
+    lib().orc_rd_fixed(_p(beats), ch, C.byref(cfg), log2nd, ref_d, guard_d, window_d, _p(out),
+                       _p(mag) if want_mag else None, n_threads)
+    return (out, mag) if want_mag else out
 
 
 def tester_stim_cfg(start_value=16, ram0=0x24000000, **kw) -> OrcStimCfg:

@@ -243,10 +243,24 @@ static int cell_index(int k, int off, int n, int edge) {
  *   - cells outside the frame read 0 (edge 0) or wrap (edge 1).
  * Output word: Tester:163-167.
  */
+/* statistic -> threshold (spec section 5: alignment by floor shifts, saturation to protoThreshold's range) */
+static int64_t threshold_fixed(int64_t stat, const orc_cfg* c) {
+  int64_t tmax = ((int64_t)1 << (c->w_thr - 1)) - 1, tmin = -((int64_t)1 << (c->w_thr - 1));
+  int64_t thr;
+  if (c->linear) {
+    thr = trim_shift(stat * (int64_t)c->scaler, c->bp_in + c->bp_scaler - c->bp_thr, ORC_TRIM_FLOOR);
+  } else {
+    thr = trim_shift(stat, c->bp_in - c->bp_thr, ORC_TRIM_FLOOR) +
+          trim_shift((int64_t)c->scaler, c->bp_scaler - c->bp_thr, ORC_TRIM_FLOOR);
+  }
+  if (thr > tmax) thr = tmax;
+  if (thr < tmin) thr = tmin;
+  return thr;
+}
+
 void orc_cfar_fixed(const int32_t* mag, const orc_cfg* c, uint32_t* out_words, int32_t* thr_out) {
   int n = 1 << c->log2n, R = c->ref_window, G = c->guard_window;
   int32_t* win = (int32_t*)malloc(sizeof(int32_t) * (size_t)(R > 0 ? R : 1));
-  int64_t tmax = ((int64_t)1 << (c->w_thr - 1)) - 1, tmin = -((int64_t)1 << (c->w_thr - 1));
   for (int k = 0; k < n; k++) {
     int64_t stat_side[2];
     for (int side = 0; side < 2; side++) { /* 0 = lagging (k-d), 1 = leading (k+d) */
@@ -288,16 +302,7 @@ void orc_cfar_fixed(const int32_t* mag, const orc_cfg* c, uint32_t* out_words, i
         stat = a < b ? a : b;
         break;
     }
-    int64_t thr;
-    if (c->linear) {
-      thr = trim_shift(stat * (int64_t)c->scaler, c->bp_in + c->bp_scaler - c->bp_thr,
-                       ORC_TRIM_FLOOR);
-    } else {
-      thr = trim_shift(stat, c->bp_in - c->bp_thr, ORC_TRIM_FLOOR) +
-            trim_shift((int64_t)c->scaler, c->bp_scaler - c->bp_thr, ORC_TRIM_FLOOR);
-    }
-    if (thr > tmax) thr = tmax;
-    if (thr < tmin) thr = tmin;
+    int64_t thr = threshold_fixed(stat, c);
     int64_t cut = mag[k];
     int peak = cut * ((int64_t)1 << c->bp_thr) > thr * ((int64_t)1 << c->bp_in);
     if (c->peak_grouping) {
@@ -621,6 +626,104 @@ void orc_rd_f32in(const float* in, size_t n_ch, const orc_rdcfg* c, double* thr,
   }
   free(twr);
   free(twd);
+}
+
+/* 2-D chain on the FIXED16 data path (BUILD-DEFINED like the float one: no reference counterpart).
+ * Range FFT per row and Doppler FFT per column with the arithmetic of orc_fft_fixed (1-bit trim per stage, Q2.14
+ * twiddles, c->trim; stage options not supported), windows in Q1.15 as in orc_chain_fixed (the Doppler window is
+ * applied to the range spectrum), magnitude = orc_mag_fixed, 2-D CFAR over the same training region as orc_rd_f32in
+ * in integer arithmetic: CA: statistic = training sum >> div_sum; GO / SO: each half's sum >> (div_sum - 1) (a half
+ * holds half the cells; div_sum = 0 shifts by 0), the greater / smaller; threshold, saturation and peak test as
+ * orc_cfar_fixed; word = orc_pack_out(threshold, range bin, peak, log2nr).  c->log2n = log2nr, c->ref_window /
+ * guard_window = the range half-widths, c->window = the range window. */
+void orc_rd_fixed(const uint32_t* in_beats, size_t n_ch, const orc_cfg* c, int log2nd, int ref_d, int guard_d,
+                  int window_d, uint32_t* out_words, int32_t* mag_out, int n_threads) {
+  int log2nr = c->log2n, nr = 1 << log2nr, nd = 1 << log2nd;
+  size_t map = (size_t)nr * (size_t)nd;
+  int ref_r = c->ref_window, guard_r = c->guard_window;
+  int hr = ref_r + guard_r, hd = ref_d + guard_d;
+  int er = nr + 2 * hr, ed = nd + 2 * hd;
+  (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(n_threads > 0 ? n_threads : 1)
+#endif
+  for (long ch = 0; ch < (long)n_ch; ch++) {
+    int16_t* re = (int16_t*)malloc(sizeof(int16_t) * 2 * map);
+    int16_t* im = re + map;
+    int big = nr > nd ? nr : nd;
+    int16_t* t = (int16_t*)malloc(sizeof(int16_t) * 4 * (size_t)big);
+    int16_t *ti = t + big, *fr = t + 2 * big, *fi = t + 3 * big;
+    int32_t* m = (int32_t*)malloc(sizeof(int32_t) * map);
+    int64_t* sat = (int64_t*)calloc((size_t)(er + 1) * (size_t)(ed + 1), sizeof(int64_t));
+    const uint32_t* src = in_beats + map * (size_t)ch;
+    for (int d = 0; d < nd; d++) { /* range FFT along r */
+      for (int r = 0; r < nr; r++) {
+        orc_unpack_iq(src[(size_t)d * (size_t)nr + (size_t)r], &t[r], &ti[r]);
+        if (c->window != ORC_WIN_NONE) {
+          int32_t wq = (int32_t)lround(orc_window_coeff(c->window, r, nr) * 32767.0);
+          t[r] = (int16_t)(((int32_t)t[r] * wq + (1 << 14)) >> 15);
+          ti[r] = (int16_t)(((int32_t)ti[r] * wq + (1 << 14)) >> 15);
+        }
+      }
+      orc_fft_fixed_ex(t, ti, log2nr, c->trim, 0, 0, 0, re + (size_t)d * (size_t)nr, im + (size_t)d * (size_t)nr);
+    }
+    for (int r = 0; r < nr; r++) { /* Doppler FFT along d */
+      for (int d = 0; d < nd; d++) {
+        t[d] = re[(size_t)d * (size_t)nr + (size_t)r];
+        ti[d] = im[(size_t)d * (size_t)nr + (size_t)r];
+        if (window_d != ORC_WIN_NONE) {
+          int32_t wq = (int32_t)lround(orc_window_coeff(window_d, d, nd) * 32767.0);
+          t[d] = (int16_t)(((int32_t)t[d] * wq + (1 << 14)) >> 15);
+          ti[d] = (int16_t)(((int32_t)ti[d] * wq + (1 << 14)) >> 15);
+        }
+      }
+      orc_fft_fixed_ex(t, ti, log2nd, c->trim, 0, 0, 0, fr, fi);
+      for (int d = 0; d < nd; d++) m[(size_t)d * (size_t)nr + (size_t)r] = orc_mag_fixed(fr[d], fi[d], c);
+    }
+    if (mag_out) memcpy(mag_out + map * (size_t)ch, m, sizeof(int32_t) * map);
+    for (int d = 0; d < ed; d++) { /* summed-area table over the halo-extended map */
+      int64_t rowsum = 0;
+      int sd = (((d - hd) % nd) + nd) % nd; /* Doppler always cyclic */
+      for (int r = 0; r < er; r++) {
+        int sr = cell_index(r - hr, 0, nr, c->edge);
+        rowsum += sr < 0 ? 0 : (int64_t)m[(size_t)sd * (size_t)nr + (size_t)sr];
+        sat[(size_t)(d + 1) * (size_t)(er + 1) + (size_t)(r + 1)] = sat[(size_t)d * (size_t)(er + 1) + (size_t)(r + 1)] + rowsum;
+      }
+    }
+#define BOX(d0, d1, r0, r1) /* inclusive ext coords */                               \
+  (sat[(size_t)((d1) + 1) * (size_t)(er + 1) + (size_t)((r1) + 1)] -                 \
+   sat[(size_t)(d0) * (size_t)(er + 1) + (size_t)((r1) + 1)] -                       \
+   sat[(size_t)((d1) + 1) * (size_t)(er + 1) + (size_t)(r0)] +                       \
+   sat[(size_t)(d0) * (size_t)(er + 1) + (size_t)(r0)])
+    for (int d = 0; d < nd; d++) {
+      for (int r = 0; r < nr; r++) {
+        int cd = d + hd, cr = r + hr, gd = guard_d, gr = guard_r;
+        int64_t stat;
+        if (c->cfar_mode == ORC_CFAR_CA) {
+          stat = (BOX(cd - hd, cd + hd, cr - hr, cr + hr) - BOX(cd - gd, cd + gd, cr - gr, cr + gr)) >> c->div_sum;
+        } else {
+          int64_t lag = BOX(cd - hd, cd + hd, cr - hr, cr - 1) - (gr > 0 ? BOX(cd - gd, cd + gd, cr - gr, cr - 1) : 0) +
+                        BOX(cd - hd, cd - gd - 1, cr, cr);
+          int64_t lead = BOX(cd - hd, cd + hd, cr + 1, cr + hr) - (gr > 0 ? BOX(cd - gd, cd + gd, cr + 1, cr + gr) : 0) +
+                         BOX(cd + gd + 1, cd + hd, cr, cr);
+          int sh = c->div_sum > 0 ? c->div_sum - 1 : 0;
+          lag >>= sh;
+          lead >>= sh;
+          stat = c->cfar_mode == ORC_CFAR_GO ? (lag > lead ? lag : lead) : (lag < lead ? lag : lead);
+        }
+        int64_t thr = threshold_fixed(stat, c);
+        int64_t cut = m[(size_t)d * (size_t)nr + (size_t)r];
+        int peak = cut * ((int64_t)1 << c->bp_thr) > thr * ((int64_t)1 << c->bp_in);
+        out_words[map * (size_t)ch + (size_t)d * (size_t)nr + (size_t)r] =
+            orc_pack_out((uint32_t)(int32_t)thr, (uint32_t)r, (uint32_t)peak, log2nr);
+      }
+    }
+#undef BOX
+    free(re);
+    free(t);
+    free(m);
+    free(sat);
+  }
 }
 
 /* ------------------------------------------------------------------ PLFG -> NCO stimulus */

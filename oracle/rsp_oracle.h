@@ -168,6 +168,12 @@ typedef struct orc_rdcfg {
 void orc_rd_f32in(const float* in, size_t n_ch, const orc_rdcfg* c, double* thr, uint8_t* peak,
                   double* margin, double* mag_out /* may be NULL */, int n_threads);
 
+/* The 2-D chain on the FIXED16 data path (see rsp_oracle.c): c carries the 1-D register file (log2n = log2nr,
+ * ref_window / guard_window = range half-widths, window = range window); out_words n_ch x nd x nr;
+ * mag_out (n_ch x nd x nr int32) may be NULL. */
+void orc_rd_fixed(const uint32_t* in_beats, size_t n_ch, const orc_cfg* c, int log2nd, int ref_d, int guard_d,
+                  int window_d, uint32_t* out_words, int32_t* mag_out, int n_threads);
+
 /* ---- PLFG -> NCO stimulus of the full chain (RspChain.scala:41-42,57-58) -------------------
  * BUILD-DEFINED model (generators/plfg and generators/nco are empty submodules), anchored on
  * FixedPLFGParams / FixedNCOParams (RspChain.scala:84-106), the tester's register program

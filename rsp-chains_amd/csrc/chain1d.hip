@@ -100,69 +100,6 @@ __device__ __forceinline__ float mag_f32(f32x2 z, int mode) {
   return __log2f(fmaxf(jpl, FLT_MIN));
 }
 
-__device__ __forceinline__ int jpl_fx(int re, int im) {
-  const int ar = re < 0 ? -re : re, ai = im < 0 ? -im : im;
-  const int u = max(ar, ai), v = min(ar, ai);
-  const int m = max(u + (v >> 3), ((7 * u) >> 3) + (v >> 1));
-  return min(m, 32767);
-}
-
-__device__ __forceinline__ int mag_fx(int re, int im, const ChainRegs& rg,
-                                      const int16_t* __restrict__ log_lut) {
-  if (rg.mag_mode == 2) return jpl_fx(re, im);
-  if (rg.mag_mode == 0) {
-    const long long s = ((long long)re * re + (long long)im * im) >> rg.bp_data;
-    return (int)(s > 32767 ? 32767 : s);
-  }
-  int x = jpl_fx(re, im);
-  x = x < 1 ? 1 : x;
-  const int e = 31 - __clz(x);
-  const int lw = rg.lut_w;
-  unsigned f = e >= lw ? ((unsigned)x >> (e - lw)) : ((unsigned)x << (lw - e));
-  f &= (1u << lw) - 1u;
-  return (e - rg.bp_data) * (1 << rg.bp_log) + (int)log_lut[f];
-}
-
-// ---------------------------------------------------------------- CFAR arithmetic
-
-template <typename V>
-struct CfarMath;
-
-template <>
-struct CfarMath<float> {
-  static __device__ __forceinline__ float side(float sum, const ChainRegs& rg) { return sum * rg.div_f; }
-  static __device__ __forceinline__ float half_sum(float a, float b) { return 0.5f * (a + b); }
-  // thr = stat * A + B with (A, B) = (scaler, 0) linear or (1, scaler) log: both exact
-  static __device__ __forceinline__ uint32_t finish(float stat, float cut, bool group_ok, int k,
-                                                    int log2n, const ChainRegs& rg) {
-    (void)k; (void)log2n;
-    const float A = rg.linear ? rg.scaler_f : 1.0f, B = rg.linear ? 0.0f : rg.scaler_f;
-    const float thr = __fmaf_rn(stat, A, B);
-    const uint32_t peak = (cut > thr) && group_ok;
-    return (__float_as_uint(thr) & ~1u) | peak;
-  }
-};
-
-template <>
-struct CfarMath<int> {
-  static __device__ __forceinline__ int side(int sum, const ChainRegs& rg) { return sum >> rg.div_sum; }
-  static __device__ __forceinline__ int half_sum(int a, int b) { return (a + b) >> 1; }
-  // branch-free: both domains computed, selected by the (uniform) logOrLinearMode register.
-  // Ranges: magnitudes are 16-bit, so cut / thr products below fit 32 bits; stat * scaler needs 64.
-  static __device__ __forceinline__ uint32_t finish(int stat, int cut, bool group_ok, int k,
-                                                    int log2n, const ChainRegs& rg) {
-    const long long prod = ((long long)stat * (long long)rg.scaler_raw) << rg.lin_shl;
-    const long long lin64 = prod >> rg.lin_shr;  // arithmetic: floor, as the spec's trim_shift
-    const int lin = lin64 > (long long)rg.tmax ? rg.tmax : (lin64 < (long long)rg.tmin ? rg.tmin : (int)lin64);
-    int lg = ((stat << rg.log_shl) >> rg.log_shr) + rg.log_scaler;
-    lg = min(max(lg, rg.tmin), rg.tmax);
-    const int thr = rg.linear ? lin : lg;
-    // cut * 2^bp_thr > thr * 2^bp_in, both sides within 31 bits (16-bit values, shifts <= 15)
-    const uint32_t peak = ((cut * (1 << rg.bp_thr)) > (thr * (1 << rg.bp_in))) && group_ok;
-    return ((uint32_t)thr << (log2n + 1)) | ((uint32_t)k << 1) | peak;
-  }
-};
-
 // lane l receives the value of lane l - S of its 16-lane row, 0 for the first S lanes
 template <int S, typename V>
 __device__ __forceinline__ V row_shr(V v) {
@@ -285,7 +222,6 @@ __device__ __forceinline__ void front_end(const void* __restrict__ in, uint32_t 
       for (int e = 0; e < 16; ++e) mg[e] = mag_f32(x[e] * scale, 1);
     }
   } else {
-    uint32_t* buf = reinterpret_cast<uint32_t*>(fbase);
     const uint32_t* twq = reinterpret_cast<const uint32_t*>(tw);
     int xr[16], xi[16];
     {
@@ -313,85 +249,7 @@ __device__ __forceinline__ void front_end(const void* __restrict__ in, uint32_t 
     // twiddle ROM -> LDS once per workgroup (the sample loads above are already in flight)
     for (int i = threadIdx.x; i < N / 2; i += wg_size(M)) rom[i] = twq[i];
     __syncthreads();
-    auto run = [&](auto conv_c) {
-      constexpr bool CONV = decltype(conv_c)::value;
-      pass_fx<M, 0, CONV>(xr, xi, tau, rom, rg);
-      auto exchange = [&](auto pc) {
-        constexpr int P = decltype(pc)::value;
-        constexpr int W0 = plan_w(M, P - 1), LO0 = plan_lo(M, P - 1);
-        constexpr int W1 = plan_w(M, P), LO1 = plan_lo(M, P);
-        constexpr bool LAST = P == NP - 1;
-#pragma unroll
-        for (int g = 0; g < (16 >> W0); ++g) {
-          uint32_t* b0 = buf + slot_base<M, LO0, W0, LAST>(tau, g);
-#pragma unroll
-          for (int r = 0; r < (1 << W0); ++r) {
-            const int e = g * (1 << W0) + r;
-            b0[slot_delta<M, LO0, W0>(r)] = ((uint32_t)xr[e] << 16) | ((uint32_t)xi[e] & 0xffffu);
-          }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int g = 0; g < (16 >> W1); ++g) {
-          const uint32_t* b1 = buf + slot_base<M, LO1, W1, LAST>(tau, g);
-#pragma unroll
-          for (int r = 0; r < (1 << W1); ++r) {
-            const uint32_t b = b1[slot_delta<M, LO1, W1>(r)];
-            xr[g * (1 << W1) + r] = (int)(short)(b >> 16);
-            xi[g * (1 << W1) + r] = (int)(short)(b & 0xffffu);
-          }
-        }
-        pass_fx<M, P, CONV>(xr, xi, tau, rom, rg);
-      };
-      exchange(std::integral_constant<int, 1>{});
-      if constexpr (NP > 2) exchange(std::integral_constant<int, 2>{});
-      if constexpr (NP > 3) exchange(std::integral_constant<int, 3>{});
-    };
-    // expandLogic / keepMSBorLSB = false somewhere: generic stages, 8-byte exchange slots (words grow past 16 bits)
-    auto run_opt = [&]() {
-      uint2* wbuf = reinterpret_cast<uint2*>(fbase);
-      pass_fx_opt<M, 0>(xr, xi, tau, rom, rg);
-      auto exchange = [&](auto pc) {
-        constexpr int P = decltype(pc)::value;
-        constexpr int W0 = plan_w(M, P - 1), LO0 = plan_lo(M, P - 1);
-        constexpr int W1 = plan_w(M, P), LO1 = plan_lo(M, P);
-        constexpr bool LAST = P == NP - 1;
-#pragma unroll
-        for (int g = 0; g < (16 >> W0); ++g) {
-          uint2* b0 = wbuf + slot_base<M, LO0, W0, LAST>(tau, g);
-#pragma unroll
-          for (int r = 0; r < (1 << W0); ++r) {
-            const int e = g * (1 << W0) + r;
-            b0[slot_delta<M, LO0, W0>(r)] = make_uint2((uint32_t)xr[e], (uint32_t)xi[e]);
-          }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int g = 0; g < (16 >> W1); ++g) {
-          const uint2* b1 = wbuf + slot_base<M, LO1, W1, LAST>(tau, g);
-#pragma unroll
-          for (int r = 0; r < (1 << W1); ++r) {
-            const uint2 b = b1[slot_delta<M, LO1, W1>(r)];
-            xr[g * (1 << W1) + r] = (int)b.x;
-            xi[g * (1 << W1) + r] = (int)b.y;
-          }
-        }
-        pass_fx_opt<M, P>(xr, xi, tau, rom, rg);
-      };
-      exchange(std::integral_constant<int, 1>{});
-      if constexpr (NP > 2) exchange(std::integral_constant<int, 2>{});
-      if constexpr (NP > 3) exchange(std::integral_constant<int, 3>{});
-      // the 2 x 16-bit stream to the magnitude block carries the 16 MSBs of a grown word
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        xr[e] = (int)(short)(xr[e] >> rg.growth);
-        xi[e] = (int)(short)(xi[e] >> rg.growth);
-      }
-    };
-    // convergent (the default trim) has a 3-op closed form; floor / half-up share the generic one
-    if (rg.keep_lsb_mask | rg.expand_mask) run_opt();
-    else if (rg.trim_conv) run(std::true_type{});
-    else run(std::false_type{});
+    fft_fx_frame<M>(xr, xi, tau, fbase, rom, rg);
     if (rg.mag_mode == 2) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) mg[e] = jpl_fx(xr[e], xi[e]);

@@ -42,12 +42,14 @@ struct Rd2dLaunch {
   int ref_d, guard_d;   // Doppler training / guard half-widths
   const void* tw_range;
   const void* tw_doppler;
-  const void* win_doppler;  // slow-time window coefficients (float), or NULL; the fast-time one is regs.window
+  const void* win_doppler;  // slow-time window coefficients (float / Q1.15), or NULL; the fast-time one is regs.window
   void* scratch_complex;  // device: n_ch * nd * nr * 8 B
   float* scratch_mag;     // device: n_ch * nd * nr * 4 B
   hipStream_t stream;
   int device;
   bool force_tiled_cfar;  // tests: take the run-time-window kernel even for the compile-time windows
+  bool fixed;             // FIXED16 data path: beats in, ROM / Q1.15 windows, int32 magnitudes, integer CFAR
+  const int16_t* log_lut; // FIXED16: log2 look-up table of the magnitude block
   size_t chunk_bytes;     // intermediates (12 B/cell) per chunk of channels; 0 = the whole batch at once
   // optional fused detection list: the CFAR kernel appends its peak cells itself (one device-scope
   // atomic per PEAK, none otherwise), so no second pass over the dense words is needed

@@ -149,6 +149,106 @@ doppler_mag_kernel(const f32x2* __restrict__ in, float* __restrict__ mag, uint32
   }
 }
 
+// ---------------------------------------------------------------- FIXED16 passes (build extension, oracle: orc_rd_fixed)
+// The same two passes on the 16-bit FixedPoint data path: beats {re[31:16], im[15:0]} in, the range spectrum kept as
+// beats (4 B/cell), both FFTs with the stage-exact arithmetic of fft_fx_frame (Q2.14 ROM in LDS), Q1.15 windows,
+// magnitudes (mag_fx) as int32.
+template <int M>
+__global__ void __launch_bounds__(wg_size(M))
+range_fx_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n_rows, uint32_t nd, uint32_t tile,
+                const uint32_t* __restrict__ twq, ChainRegs rg, uint32_t* __restrict__ zero_count) {
+  constexpr int N = 1 << M, T = threads_per_frame(M), FPW = frames_per_wg(M);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, fl = tid / T, tau = tid % T;
+  const uint32_t row = blockIdx.x * FPW + fl;
+  const bool live = row < n_rows;
+  if (zero_count && blockIdx.x == 0 && tid == 0) zero_count[0] = zero_count[1] = 0u;
+  unsigned char* fbase = smem + (size_t)fl * fft_image_slots(M) * 4;
+  uint32_t* rom = reinterpret_cast<uint32_t*>(smem + (size_t)FPW * fft_image_slots(M) * 4);
+  const uint32_t* src = in + (size_t)(live ? row : 0) * N + first_sample<M>(tau);
+  int xr[16], xi[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const uint32_t b = src[sample_offset<M>(e)];
+    xr[e] = (int)(short)(b >> 16);
+    xi[e] = (int)(short)(b & 0xffffu);
+  }
+  if (rg.window) {  // Q1.15 coefficient, product rounded half-up back to 16 bits (spec section 2.1)
+    const int16_t* wt = reinterpret_cast<const int16_t*>(rg.window) + first_sample<M>(tau);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int wq = wt[sample_offset<M>(e)];
+      xr[e] = (int)(short)((xr[e] * wq + (1 << 14)) >> 15);
+      xi[e] = (int)(short)((xi[e] * wq + (1 << 14)) >> 15);
+    }
+  }
+  for (int i = tid; i < N / 2; i += wg_size(M)) rom[i] = twq[i];
+  __syncthreads();
+  fft_fx_frame<M>(xr, xi, tau, fbase, rom, rg);
+  constexpr int NP = plan_np(M), WL = plan_w(M, NP - 1);
+  if (!live) return;
+  const uint32_t ch = row / nd, d = row % nd;
+  uint32_t* dst = out + (size_t)ch * nd * N + map_index(d, tau, nd, N, tile);
+  const size_t step = tile ? (size_t)nd : 1;
+#pragma unroll
+  for (int g = 0; g < (16 >> WL); ++g) {
+#pragma unroll
+    for (int p = 0; p < (1 << WL); ++p) {
+      const int e = g * (1 << WL) + p;
+      dst[(size_t)((bitrev_c(p, WL) << (M - WL)) + g * T) * step] = ((uint32_t)xr[e] << 16) | ((uint32_t)xi[e] & 0xffffu);
+    }
+  }
+}
+
+constexpr int kFxCols = 16;  // range bins per workgroup of the FIXED16 Doppler pass
+constexpr int kFxColBytes(int MD) { return 4 * fft_image_slots(MD) + 16; }
+
+template <int MD>
+__global__ void __launch_bounds__(threads_per_frame(MD) * kFxCols)
+doppler_fx_kernel(const uint32_t* __restrict__ in, int32_t* __restrict__ mag, uint32_t nr, uint32_t tile,
+                  const uint32_t* __restrict__ twq, const int16_t* __restrict__ win, const int16_t* __restrict__ log_lut,
+                  ChainRegs rg) {
+  constexpr int ND = 1 << MD, T = threads_per_frame(MD), C = kFxCols;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, fl = tid % C, tau = tid / C;
+  const uint32_t groups_per_ch = nr / C;
+  const uint32_t ch = blockIdx.x / groups_per_ch, r0 = (blockIdx.x % groups_per_ch) * C;
+  unsigned char* fbase = smem + (size_t)fl * kFxColBytes(MD);
+  uint32_t* rom = reinterpret_cast<uint32_t*>(smem + (size_t)C * kFxColBytes(MD));
+  const size_t col = (size_t)ch * ND * nr + map_index(0, r0 + fl, ND, nr, tile);
+  const uint32_t pitch = tile ? kTileCols : nr;
+  const uint32_t* src = in + col + (size_t)first_sample<MD>(tau) * pitch;
+  int xr[16], xi[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const uint32_t b = src[(size_t)sample_offset<MD>(e) * pitch];
+    xr[e] = (int)(short)(b >> 16);
+    xi[e] = (int)(short)(b & 0xffffu);
+  }
+  if (win) {
+    const int16_t* wt = win + first_sample<MD>(tau);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int wq = wt[sample_offset<MD>(e)];
+      xr[e] = (int)(short)((xr[e] * wq + (1 << 14)) >> 15);
+      xi[e] = (int)(short)((xi[e] * wq + (1 << 14)) >> 15);
+    }
+  }
+  for (int i = tid; i < ND / 2; i += T * C) rom[i] = twq[i];
+  __syncthreads();
+  fft_fx_frame<MD>(xr, xi, tau, fbase, rom, rg);
+  constexpr int NP = plan_np(MD), WL = plan_w(MD, NP - 1);
+  int32_t* dst = mag + col;
+#pragma unroll
+  for (int g = 0; g < (16 >> WL); ++g) {
+#pragma unroll
+    for (int p = 0; p < (1 << WL); ++p) {
+      const int e = g * (1 << WL) + p;
+      dst[(size_t)bin_of<MD>(tau, g, p) * pitch] = mag_fx(xr[e], xi[e], rg, log_lut);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- fused detection list
 // d_count = {found, stored} is the list's own cursor: the range pass (first launch of the batch) zeroes it, a wave /
 // cell that found peaks reserves its entries with ONE returning device-scope atomic on found and folds
@@ -179,33 +279,36 @@ constexpr int kTD = 32, kTR = 64;  // output tile: 32 Doppler rows x 64 range bi
 
 // SRR/SGR/SRD/SGD >= 0: window half-widths fixed at compile time (loops unroll, LDS offsets become
 // immediates: ~2.5x fewer instructions); -1: taken from the run-time arguments.
-template <int SRR, int SGR, int SRD, int SGD>
+template <int SRR, int SGR, int SRD, int SGD, typename T = float>
 __global__ void __launch_bounds__(256)
-cfar2d_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_t nd, uint32_t nr,
+cfar2d_kernel(const T* __restrict__ mag, uint32_t* __restrict__ out, uint32_t nd, uint32_t nr,
               int ref_r_rt, int guard_r_rt, int ref_d_rt, int guard_d_rt, int edge, float kA, float kB,
               rsp_detection* __restrict__ det_list, uint32_t det_cap, uint32_t* __restrict__ det_count, uint32_t ch_base,
-              int mode, uint32_t tile) {
+              int mode, uint32_t tile, ChainRegs rg, int log2nr) {
+  // T = float: thresholds kA * sum / count + kB.  T = int32_t (FIXED16 magnitudes): integer sums, the statistic and
+  // threshold rules of orc_rd_fixed through CfarMath<int> (rg).
+  constexpr bool FX = !std::is_same<T, float>::value;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int ref_r = SRR >= 0 ? SRR : ref_r_rt, guard_r = SGR >= 0 ? SGR : guard_r_rt;
   const int ref_d = SRD >= 0 ? SRD : ref_d_rt, guard_d = SGD >= 0 ? SGD : guard_d_rt;
   const int hr = ref_r + guard_r, hd = ref_d + guard_d;
   const int RW = kTR + 2 * hr, RH = kTD + 2 * hd;  // haloed region
   const int MS = RW | 1;                            // odd row pitch of the magnitude region
-  float* m = reinterpret_cast<float*>(smem);        // [RH][MS]
-  float* ro = m + RH * MS;                          // outer row sums [RH][kTR + 1]
+  T* m = reinterpret_cast<T*>(smem);        // [RH][MS]
+  T* ro = m + RH * MS;                          // outer row sums [RH][kTR + 1]
   // guard-box row sums are only needed for the kTD + 2 guard_d rows around the outputs; keeping that
   // array short is what lets four workgroups share a CU's LDS
   const int ri_first = hd - guard_d, ri_rows = kTD + 2 * guard_d + 1;
-  float* ri = ro + (RH + 1) * (kTR + 1);            // [ri_rows][kTR + 1], row dd at index dd - ri_first
+  T* ri = ro + (RH + 1) * (kTR + 1);            // [ri_rows][kTR + 1], row dd at index dd - ri_first
   // GO / SO (mode 1 / 2): the same sums over the LAGGING half of each row window (columns c - h .. c - 1)
-  float* roL = ri + ri_rows * (kTR + 1);            // [RH][kTR + 1]
-  float* riL = roL + (RH + 1) * (kTR + 1);          // [ri_rows][kTR + 1]
+  T* roL = ri + ri_rows * (kTR + 1);            // [RH][kTR + 1]
+  T* riL = roL + (RH + 1) * (kTR + 1);          // [ri_rows][kTR + 1]
   const int tid = threadIdx.x;
   const uint32_t tiles_r = nr / kTR, tiles_d = nd / kTD;
   const uint32_t ch = blockIdx.x / (tiles_r * tiles_d);
   const uint32_t t = blockIdx.x % (tiles_r * tiles_d);
   const int d0 = (int)(t / tiles_r) * kTD, r0 = (int)(t % tiles_r) * kTR;
-  const float* map = mag + (size_t)ch * nd * nr;
+  const T* map = mag + (size_t)ch * nd * nr;
 
   // 1. region -> LDS: 128 lanes across a region row (coalesced along r), 2 rows per iteration
   {
@@ -215,12 +318,12 @@ cfar2d_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_
     const bool inside = rr < RW && r >= 0 && r < (int)nr;
     // batches of 16 independent loads per thread: a one-load-per-iteration loop serialises on HBM latency
     for (int base = half; base < RH; base += 32) {
-      float v[16];
+      T v[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
         const int dd = base + 2 * u;
         const int d = (d0 - hd + dd + (int)nd) & ((int)nd - 1);  // Doppler cyclic (nd is a power of two)
-        v[u] = (inside && dd < RH) ? map[map_index((uint32_t)d, (uint32_t)r, nd, nr, tile)] : 0.f;
+        v[u] = (inside && dd < RH) ? map[map_index((uint32_t)d, (uint32_t)r, nd, nr, tile)] : T(0);
       }
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
@@ -235,17 +338,17 @@ cfar2d_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_
   // all banks
   for (int task = tid; task < RH * (kTR / 16); task += 256) {
     const int dd = task % RH, c0 = (task / RH) * 16;
-    const float* row = m + dd * MS + c0 + hr;  // row[c] = cell at output column c0 + c
-    float so = row[0], si = row[0], so2 = 0.f, si2 = 0.f;  // symmetric windows: two independent chains
+    const T* row = m + dd * MS + c0 + hr;  // row[c] = cell at output column c0 + c
+    T so = row[0], si = row[0], so2 = T(0), si2 = T(0);  // symmetric windows: two independent chains
 #pragma unroll
     for (int k = 1; k <= hr; ++k) { so += row[k]; so2 += row[-k]; }
 #pragma unroll
     for (int k = 1; k <= guard_r; ++k) { si += row[k]; si2 += row[-k]; }
     so += so2;
     si += si2;
-    float* po = ro + dd * (kTR + 1) + c0;
+    T* po = ro + dd * (kTR + 1) + c0;
     const bool want_i = dd >= ri_first && dd < ri_first + ri_rows;
-    float* pi = ri + (want_i ? dd - ri_first : 0) * (kTR + 1) + c0;
+    T* pi = ri + (want_i ? dd - ri_first : 0) * (kTR + 1) + c0;
     if (mode == 0) {
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
@@ -255,9 +358,9 @@ cfar2d_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_
         si += row[c + guard_r + 1] - row[c - guard_r];
       }
     } else {
-      float* pol = roL + dd * (kTR + 1) + c0;
-      float* pil = riL + (want_i ? dd - ri_first : 0) * (kTR + 1) + c0;
-      float sol = so2, sil = si2;  // so2 / si2 = the sums over columns -h .. -1 computed above
+      T* pol = roL + dd * (kTR + 1) + c0;
+      T* pil = riL + (want_i ? dd - ri_first : 0) * (kTR + 1) + c0;
+      T sol = so2, sil = si2;  // so2 / si2 = the sums over columns -h .. -1 computed above
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
         po[c] = so;
@@ -276,9 +379,9 @@ cfar2d_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_
     const int c = tid & (kTR - 1), dseg = (tid / kTR) * (kTD / 4);
     const float count = (float)((2 * hr + 1) * (2 * hd + 1) - (2 * guard_r + 1) * (2 * guard_d + 1));
     const float kAc = kA / count;
-    const float* co = ro + (dseg + hd) * (kTR + 1) + c;  // co[k (kTR+1)] = outer row sum at output row dseg + k
-    const float* ci = ri + (dseg + hd - ri_first) * (kTR + 1) + c;
-    float so = co[0], si = ci[0], so2 = 0.f, si2 = 0.f;
+    const T* co = ro + (dseg + hd) * (kTR + 1) + c;  // co[k (kTR+1)] = outer row sum at output row dseg + k
+    const T* ci = ri + (dseg + hd - ri_first) * (kTR + 1) + c;
+    T so = co[0], si = ci[0], so2 = T(0), si2 = T(0);
 #pragma unroll
     for (int k = 1; k <= hd; ++k) { so += co[k * (kTR + 1)]; so2 += co[-k * (kTR + 1)]; }
 #pragma unroll
@@ -287,10 +390,10 @@ cfar2d_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_
     si += si2;
     uint32_t* dst = out + ((size_t)ch * nd + d0 + dseg) * nr + r0 + c;
     // GO / SO: column sums of the lagging-half row sums + the cells of the CUT's own column above the guard
-    const float* col = roL + (dseg + hd) * (kTR + 1) + c;
-    const float* cil = riL + (dseg + hd - ri_first) * (kTR + 1) + c;
-    const float* mcol = m + (dseg + hd) * MS + c + hr;  // mcol[k MS] = the CUT column at output row dseg + k
-    float sol = 0.f, sil = 0.f, up = 0.f;
+    const T* col = roL + (dseg + hd) * (kTR + 1) + c;
+    const T* cil = riL + (dseg + hd - ri_first) * (kTR + 1) + c;
+    const T* mcol = m + (dseg + hd) * MS + c + hr;  // mcol[k MS] = the CUT column at output row dseg + k
+    T sol = T(0), sil = T(0), up = T(0);
     if (mode != 0) {
       for (int k = -hd; k <= hd; ++k) sol += col[k * (kTR + 1)];
       for (int k = -guard_d; k <= guard_d; ++k) sil += cil[k * (kTR + 1)];
@@ -299,16 +402,26 @@ cfar2d_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_
     const float kAh = 2.0f * kAc;  // a half holds count / 2 cells
 #pragma unroll
     for (int j = 0; j < kTD / 4; ++j) {
-      float thr = __fmaf_rn(so - si, kAc, kB);
+      const T cut = m[(dseg + j + hd) * MS + c + hr];
+      T lag = T(0), lead = T(0);
       if (mode != 0) {
-        const float lag = sol - sil + up, lead = (so - si) - lag;
-        thr = __fmaf_rn(mode == 1 ? fmaxf(lag, lead) : fminf(lag, lead), kAh, kB);
+        lag = sol - sil + up;
+        lead = (so - si) - lag;
         sol += col[(j + hd + 1) * (kTR + 1)] - col[(j - hd) * (kTR + 1)];
         sil += cil[(j + guard_d + 1) * (kTR + 1)] - cil[(j - guard_d) * (kTR + 1)];
         up += mcol[(j - guard_d) * MS] - mcol[(j - hd) * MS];
       }
-      const float cut = m[(dseg + j + hd) * MS + c + hr];
-      const uint32_t wd = (__float_as_uint(thr) & ~1u) | (uint32_t)(cut > thr);
+      uint32_t wd;
+      if constexpr (FX) {
+        const int sh = rg.div_sum > 0 ? rg.div_sum - 1 : 0;  // a half holds half the cells
+        const int stat = mode == 0 ? (int)(so - si) >> rg.div_sum
+                       : mode == 1 ? max((int)lag >> sh, (int)lead >> sh) : min((int)lag >> sh, (int)lead >> sh);
+        wd = CfarMath<int>::finish(stat, (int)cut, true, r0 + c, log2nr, rg);
+      } else {
+        float thr = __fmaf_rn((float)(so - si), kAc, kB);
+        if (mode != 0) thr = __fmaf_rn(mode == 1 ? fmaxf((float)lag, (float)lead) : fminf((float)lag, (float)lead), kAh, kB);
+        wd = (__float_as_uint(thr) & ~1u) | (uint32_t)((float)cut > thr);
+      }
       dst[(size_t)j * nr] = wd;
       if (det_list && (wd & 1u)) append_peak(det_list, det_cap, det_count, ch_base + ch, (uint32_t)(d0 + dseg + j), (uint32_t)(r0 + c), wd);
       so += co[(j + hd + 1) * (kTR + 1)] - co[(j - hd) * (kTR + 1)];
@@ -674,13 +787,86 @@ static hipError_t launch_rd2d_chunk(const Rd2dLaunch& a, uint32_t ch0, uint32_t 
 #undef RSP_WALK
     return hipGetLastError();
   }
-  auto k = cfar2d_kernel<-1, -1, -1, -1>;
+  auto k = cfar2d_kernel<-1, -1, -1, -1, float>;
   static LdsGrant granted;
   e = grant_lds(k, lds, a.device, granted);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3(n_ch * (nr / kTR) * (nd / kTD)), dim3(256), lds, a.stream, a.scratch_mag, out,
                      nd, nr, a.regs.R, a.regs.G, a.ref_d, a.guard_d, a.regs.edge, kA, kB, a.det_list, a.det_cap,
-                     a.det_count, ch0, a.regs.cfar_mode, tile);
+                     a.det_count, ch0, a.regs.cfar_mode, tile, a.regs, a.log2nr);
+  return hipGetLastError();
+}
+
+// ---- FIXED16 data path: three launches of the same shape
+template <int M>
+static hipError_t launch_range_fx(const uint32_t* in, uint32_t* out, uint32_t n_rows, uint32_t nd, uint32_t tile,
+                                  const uint32_t* twq, const ChainRegs& rg, uint32_t* zero_count, hipStream_t s, int device) {
+  constexpr int fpw = frames_per_wg(M);
+  const size_t lds = (size_t)fpw * fft_image_slots(M) * 4 + ((size_t)1 << M) / 2 * 4;
+  auto k = range_fx_kernel<M>;
+  static LdsGrant granted;
+  hipError_t e = grant_lds(k, lds, device, granted);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k, dim3((n_rows + fpw - 1) / fpw), dim3(wg_size(M)), lds, s, in, out, n_rows, nd, tile, twq, rg, zero_count);
+  return hipGetLastError();
+}
+template <int MD>
+static hipError_t launch_doppler_fx(const uint32_t* in, int32_t* mag, uint32_t n_ch, uint32_t nr, uint32_t tile,
+                                    const uint32_t* twq, const int16_t* win, const int16_t* log_lut, const ChainRegs& rg,
+                                    hipStream_t s, int device) {
+  const size_t lds = (size_t)kFxColBytes(MD) * kFxCols + ((size_t)1 << MD) / 2 * 4;
+  auto k = doppler_fx_kernel<MD>;
+  static LdsGrant granted;
+  hipError_t e = grant_lds(k, lds, device, granted);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k, dim3(n_ch * (nr / kFxCols)), dim3(threads_per_frame(MD) * kFxCols), lds, s, in, mag, nr, tile, twq, win,
+                     log_lut, rg);
+  return hipGetLastError();
+}
+
+static hipError_t launch_rd2d_chunk_fx(const Rd2dLaunch& a, uint32_t ch0, uint32_t n_ch) {
+  const uint32_t nr = 1u << a.log2nr, nd = 1u << a.log2nd;
+  const size_t map = (size_t)nr * nd;
+  hipError_t e;
+  const uint32_t* in = reinterpret_cast<const uint32_t*>(a.in) + (size_t)ch0 * map;
+  uint32_t* out = a.out + (size_t)ch0 * map;
+  uint32_t* x1 = reinterpret_cast<uint32_t*>(a.scratch_complex);
+  int32_t* mag = reinterpret_cast<int32_t*>(a.scratch_mag);
+  const uint32_t* twr = reinterpret_cast<const uint32_t*>(a.tw_range);
+  const uint32_t* twd = reinterpret_cast<const uint32_t*>(a.tw_doppler);
+  const uint32_t rows = n_ch * nd, tile = rd_tile(a.log2nr);
+  uint32_t* zero_count = (a.det_list && ch0 == 0) ? a.det_count : nullptr;
+  switch (a.log2nr) {
+    case 8: e = launch_range_fx<8>(in, x1, rows, nd, tile, twr, a.regs, zero_count, a.stream, a.device); break;
+    case 9: e = launch_range_fx<9>(in, x1, rows, nd, tile, twr, a.regs, zero_count, a.stream, a.device); break;
+    case 10: e = launch_range_fx<10>(in, x1, rows, nd, tile, twr, a.regs, zero_count, a.stream, a.device); break;
+    case 11: e = launch_range_fx<11>(in, x1, rows, nd, tile, twr, a.regs, zero_count, a.stream, a.device); break;
+    case 12: e = launch_range_fx<12>(in, x1, rows, nd, tile, twr, a.regs, zero_count, a.stream, a.device); break;
+    case 13: e = launch_range_fx<13>(in, x1, rows, nd, tile, twr, a.regs, zero_count, a.stream, a.device); break;
+    default: return hipErrorInvalidValue;
+  }
+  if (e != hipSuccess) return e;
+  ChainRegs rd = a.regs;  // the Doppler FFT has no window of its own in the register file
+  rd.window = nullptr;
+  const int16_t* wd = reinterpret_cast<const int16_t*>(a.win_doppler);
+  switch (a.log2nd) {
+    case 8: e = launch_doppler_fx<8>(x1, mag, n_ch, nr, tile, twd, wd, a.log_lut, rd, a.stream, a.device); break;
+    case 9: e = launch_doppler_fx<9>(x1, mag, n_ch, nr, tile, twd, wd, a.log_lut, rd, a.stream, a.device); break;
+    case 10: e = launch_doppler_fx<10>(x1, mag, n_ch, nr, tile, twd, wd, a.log_lut, rd, a.stream, a.device); break;
+    default: return hipErrorInvalidValue;
+  }
+  if (e != hipSuccess) return e;
+  const int hr = a.regs.R + a.regs.G, hd = a.ref_d + a.guard_d;
+  const size_t lds = 4 * ((size_t)(kTD + 2 * hd) * ((kTR + 2 * hr) | 1) +
+                          (a.regs.cfar_mode ? 2 : 1) * ((size_t)(kTD + 2 * hd + 1) * (kTR + 1) + (size_t)(kTD + 2 * a.guard_d + 1) * (kTR + 1)));
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  auto k = cfar2d_kernel<-1, -1, -1, -1, int32_t>;
+  static LdsGrant granted;
+  e = grant_lds(k, lds, a.device, granted);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k, dim3(n_ch * (nr / kTR) * (nd / kTD)), dim3(256), lds, a.stream, mag, out,
+                     nd, nr, a.regs.R, a.regs.G, a.ref_d, a.guard_d, a.regs.edge, 0.f, 0.f, a.det_list, a.det_cap,
+                     a.det_count, ch0, a.regs.cfar_mode, tile, a.regs, a.log2nr);
   return hipGetLastError();
 }
 
@@ -691,7 +877,8 @@ hipError_t launch_rd2d(const Rd2dLaunch& a) {
   if (a.n_ch == 0) return a.det_list ? hipMemsetAsync(a.det_count, 0, 2 * sizeof(uint32_t), a.stream) : hipSuccess;
   const uint32_t per = rd2d_chunk_channels(a.log2nr, a.log2nd, a.n_ch, a.chunk_bytes);
   for (uint32_t c0 = 0; c0 < a.n_ch; c0 += per) {
-    hipError_t e = launch_rd2d_chunk(a, c0, a.n_ch - c0 < per ? a.n_ch - c0 : per);
+    const uint32_t n = a.n_ch - c0 < per ? a.n_ch - c0 : per;
+    hipError_t e = a.fixed ? launch_rd2d_chunk_fx(a, c0, n) : launch_rd2d_chunk(a, c0, n);
     if (e != hipSuccess) return e;
   }
   return hipSuccess;

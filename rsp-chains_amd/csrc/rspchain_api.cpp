@@ -166,7 +166,8 @@ int validate(const rsp_chain_params* p) {
   }
   if (p->cfarAddress.mask < 4 * kNumCfarRegs - 1) return fail(RSP_ERR_INVALID, "cfarAddress mask 0x%x too small for 12 registers", p->cfarAddress.mask);
   if (p->dopplerPoints != 0) {  // 2-D range-Doppler chain (no reference counterpart; BASELINE.json configs 3/5)
-    if (p->dtype != RSP_DTYPE_F32) return fail(RSP_ERR_UNSUPPORTED, "the 2-D chain is implemented for RSP_DTYPE_F32 only");
+    if (p->dtype != RSP_DTYPE_F32 && stage_opts)
+      return fail(RSP_ERR_UNSUPPORTED, "2-D chain, FIXED16: expandLogic / keepMSBorLSB stage options are defined for the 1-D chain only");
     if (!is_pow2(p->dopplerPoints) || p->dopplerPoints < 256 || p->dopplerPoints > 1024)
       return fail(RSP_ERR_UNSUPPORTED, "dopplerPoints = %d: 256, 512 or 1024", p->dopplerPoints);
     if (p->refDoppler < 1 || p->guardDoppler < 0 || p->refDoppler + p->guardDoppler > 32)
@@ -521,6 +522,8 @@ int launch_rd(rsp_chain* c, const void* d_in, size_t n_ch, uint32_t* d_out, rsp_
   a.device = c->device;
   a.force_tiled_cfar = c->opt_force_tiled;
   a.chunk_bytes = c->opt_rd_chunk_bytes;
+  a.fixed = c->p.dtype != RSP_DTYPE_F32;
+  a.log_lut = c->d_log_lut;
   if (d_found) {
     a.det_list = d_list;
     a.det_cap = cap;

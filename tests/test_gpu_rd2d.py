@@ -238,6 +238,91 @@ def test_rd2d_rejects_what_it_does_not_implement(gpu):
                                               peakGrouping=1))
         with pytest.raises(NotImplementedError):
             dut.check()
+    with pytest.raises(NotImplementedError):     # GOS has no 2-D definition
+        p = rd_params(1024, 512); p.cfarParams.CFARAlgorithm = R.GOSCFARType
+        with R.FftMagCfarChainVanilla(p) as dut:
+            dut.configure(R.RunTimeRspChainParams(fftSize=1024, refWindowSize=8, guardWindowSize=2, indexLagg=3, indexLead=3))
+            dut.check()
+
+
+# ------------------------------------------------------------------ FIXED16 data path (bit-exact vs orc_rd_fixed)
+
+def rd_params_fx(nr, nd, ref=8, guard=2, edge="zero", window=None, windowDoppler=None, trim="Convergent", bp=12):
+    fp = R.FixedPoint(16, bp)
+    return R.FftMagCfarVanillaParameters(
+        fftParams=R.FFTParams.fixed(numPoints=nr, binPoint=bp, trimType=trim), magParams=R.MAGParams.fixed(binPoint=bp),
+        cfarParams=R.CFARParams(protoIn=fp, protoThreshold=fp, protoScaler=fp, fftSize=nr, leadLaggWindowSize=16,
+                                guardWindowSize=4, edgeMode=edge),
+        dtype=R.FIXED16, dopplerPoints=nd, refDoppler=ref, guardDoppler=guard, window=window, windowDoppler=windowDoppler)
+
+
+def targets_fx(n_ch, nd, nr, seed, k=3, noise=300, amp=6000):
+    """Point targets + white noise as int16 I/Q beats (data[31:16] = re, [15:0] = im)."""
+    rng = np.random.default_rng(seed)
+    x = noise * (rng.standard_normal((n_ch, nd, nr)) + 1j * rng.standard_normal((n_ch, nd, nr)))
+    tr, td = np.arange(nr), np.arange(nd)
+    where = []
+    for ch in range(n_ch):
+        for j in range(k):
+            rb, db = int(rng.integers(0, nr)), int(rng.integers(0, nd))
+            x[ch] += amp / (j + 1) * np.exp(2j * np.pi * db * td / nd)[:, None] * np.exp(2j * np.pi * rb * tr / nr)[None, :]
+            where.append((ch, db, rb))
+    re = np.clip(np.rint(x.real), -32768, 32767).astype(np.int64)
+    im = np.clip(np.rint(x.imag), -32768, 32767).astype(np.int64)
+    return O.pack_iq(re, im).reshape(n_ch, nd, nr), where
+
+
+def fx_oracle(params, rt, beats, nd, ref_d, guard_d, window_d=None, want_mag=False):
+    from helpers import oracle_cfg, WINDOWS
+    cfg = oracle_cfg(params, rt)
+    return O.rd_fixed(beats, cfg, R.log2Up(nd), ref_d, guard_d, WINDOWS[window_d], n_threads=4, want_mag=want_mag)
+
+
+@pytest.mark.parametrize("nr,nd,edge,mode,magmode", [
+    (256, 256, "zero", "Cell Averaging", 2), (1024, 512, "wrap", "Greatest Of", 2), (512, 256, "zero", "Smallest Of", 0),
+    (2048, 256, "wrap", "Cell Averaging", 1), (4096, 512, "zero", "Cell Averaging", 2), (8192, 256, "zero", "Greatest Of", 2),
+    (1024, 1024, "zero", "Cell Averaging", 2)])
+def test_rd2d_fixed_bit_exact(gpu, nr, nd, edge, mode, magmode):
+    """The 2-D chain on the 16-bit FixedPoint data path: every output word equals the oracle's (orc_rd_fixed)."""
+    n_ch = 2
+    params = rd_params_fx(nr, nd, edge=edge)
+    rt = R.RunTimeRspChainParams(fftSize=nr, CFARMode=mode, refWindowSize=8, guardWindowSize=2, divSum=8,
+                                 thresholdScaler=3.0, magMode=magmode, logOrLinearMode=0 if magmode == 1 else 1)
+    beats, where = targets_fx(n_ch, nd, nr, seed=99 + nr + nd)
+    with R.FftMagCfarChainVanilla(params) as dut:
+        dut.configure(rt)
+        words = dut.stream(beats)
+    ref = fx_oracle(params, rt, beats, nd, 8, 2)
+    assert words.shape == ref.shape == (n_ch, nd, nr)
+    bad = np.flatnonzero(words.ravel() != ref.ravel())
+    assert bad.size == 0, f"{bad.size} words differ, first at {np.unravel_index(bad[0], words.shape)}"
+    if magmode == 2 and mode != "Greatest Of":
+        for ch, db, rb in where[:1]:       # the strongest injected target of channel 0 is a peak at its cell
+            assert words[ch, db, rb] & 1
+
+
+@pytest.mark.parametrize("rr,gr,rd,gd,mode", [(4, 1, 5, 3, "Cell Averaging"), (16, 3, 4, 0, "Greatest Of"), (2, 1, 7, 1, "Smallest Of")])
+def test_rd2d_fixed_windows_and_sizes(gpu, rr, gr, rd, gd, mode):
+    """Other window geometries, Q1.15 range + Doppler windows, half-up trim, and the fused detection list."""
+    nr, nd, n_ch = 512, 256, 3
+    params = rd_params_fx(nr, nd, ref=rd, guard=gd, edge="wrap", window="hann", windowDoppler="hamming", trim="RoundHalfUp")
+    rt = R.RunTimeRspChainParams(fftSize=nr, CFARMode=mode, refWindowSize=rr, guardWindowSize=gr, divSum=7, thresholdScaler=2.5)
+    beats, _ = targets_fx(n_ch, nd, nr, seed=5 + rr)
+    with R.FftMagCfarChainVanilla(params) as dut:
+        dut.configure(rt)
+        words = dut.stream(beats)
+        det, found = dut.detections(beats)
+    ref = fx_oracle(params, rt, beats, nd, rd, gd, window_d="hamming")
+    assert np.array_equal(words, ref)
+    ch, d, r = np.nonzero(ref & 1)
+    assert found == ch.size == det.size
+    got = sorted(zip(det["frame"].tolist(), det["doppler"].tolist(), det["bin"].tolist(), det["word"].tolist()))
+    want = sorted(zip(ch.tolist(), d.tolist(), r.tolist(), ref[ch, d, r].tolist()))
+    assert got == want
+
+
+def test_rd2d_fixed_rejects_stage_options(gpu):
+    p = rd_params_fx(256, 256)
+    p.fftParams.expandLogic[0] = 1
     with pytest.raises(NotImplementedError):
-        p = rd_params(1024, 512); p.dtype = R.FIXED16
         R.FftMagCfarChainVanilla(p)

@@ -258,3 +258,46 @@ def test_range_doppler_oracle_against_numpy():
                         if 0 <= r2 < nr:                        # range: zeros outside; Doppler: cyclic
                             tot += mref[ch, (d + dd) % nd, r2]
                 assert np.isclose(thr[ch, d, r], 3.0 * tot / cnt, rtol=1e-9)
+
+
+def test_range_doppler_fixed_oracle_from_its_parts():
+    """orc_rd_fixed restated with the 1-D pieces the KATs above pin (orc_fft_fixed, orc_mag_fixed, the threshold rule of
+    orc_cfar_fixed) and a brute-force 2-D training sum; GO >= CA-like ordering of the half statistics."""
+    nr, nd, n_ch = 32, 16, 2
+    rng = np.random.default_rng(77)
+    re = rng.integers(-6000, 6001, size=(n_ch, nd, nr)); im = rng.integers(-6000, 6001, size=(n_ch, nd, nr))
+    beats = O.pack_iq(re, im).reshape(n_ch, nd, nr)
+    cfg = O.default_cfg(log2n=5, ref_window=3, guard_window=1, div_sum=5, scaler=int(2.5 * 4096), cfar_mode=O.CFAR_CA,
+                        edge=O.EDGE_ZERO)
+    words, mag = O.rd_fixed(beats, cfg, 4, 2, 1, want_mag=True)
+    # magnitudes: rows then columns through the 1-D fixed FFT
+    rr_ = np.zeros((n_ch, nd, nr), np.int16); ri_ = np.zeros_like(rr_)
+    for ch in range(n_ch):
+        for d in range(nd):
+            rr_[ch, d], ri_[ch, d] = O.fft_fixed(re[ch, d].astype(np.int16), im[ch, d].astype(np.int16), cfg.trim)
+    mref = np.zeros((n_ch, nd, nr), np.int64)
+    for ch in range(n_ch):
+        for r in range(nr):
+            cr, ci = O.fft_fixed(rr_[ch, :, r].copy(), ri_[ch, :, r].copy(), cfg.trim)
+            mref[ch, :, r] = O.mag_fixed(cr, ci, cfg)
+    assert np.array_equal(mag, mref)
+    hr, hd = 4, 3
+    for ch in range(n_ch):
+        for d in (0, 7, 15):
+            for r in (0, 2, 16, 31):
+                tot = 0
+                for dd in range(-hd, hd + 1):
+                    for q in range(-hr, hr + 1):
+                        if abs(dd) <= 1 and abs(q) <= 1:
+                            continue
+                        if 0 <= r + q < nr:
+                            tot += int(mref[ch, (d + dd) % nd, r + q])
+                thr = ((tot >> 5) * cfg.scaler) >> cfg.bp_scaler           # bp_in = bp_thr: shift by bp_scaler
+                thr = min(thr, (1 << (cfg.w_thr - 1)) - 1)
+                w = int(words[ch, d, r])
+                assert w >> 6 == thr and (w >> 1) & 31 == r and (w & 1) == int(mref[ch, d, r] > thr)
+    cfg.cfar_mode = O.CFAR_GO
+    go = O.rd_fixed(beats, cfg, 4, 2, 1) >> 6
+    cfg.cfar_mode = O.CFAR_SO
+    so = O.rd_fixed(beats, cfg, 4, 2, 1) >> 6
+    assert np.all(go >= so) and np.any(go > so)
