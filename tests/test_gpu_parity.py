@@ -407,3 +407,34 @@ def test_small_runtime_fft_sizes(gpu, n):
     thr, peak, margin, mag = O.chain_f32(x, oracle_fcfg(paramsf, rt), want_mag=True)
     compare_f32(words, thr, peak, margin, mag)
     assert found == int((words & 1).sum())
+
+
+@pytest.mark.parametrize("frames", [3000, 20000])
+def test_fused_list_order_and_large_frame_counts(gpu, frames):
+    """Up to 16384 frames the frame compaction takes its offsets from a prefix over the frame counts: the list comes out
+    with the frames in ascending order (a frame's peaks contiguous, in staging order).  Above that, blocks of 256 frames
+    are reserved with one atomic each (any block order); both are complete."""
+    n = 256
+    params = make_params(n, leadLagg=16, guard=2)
+    rt = R.RunTimeRspChainParams(fftSize=n, refWindowSize=16, guardWindowSize=2, thresholdScaler=2.0)
+    beats = random_beats(frames, n, 31337, amp=8000)
+    cap = 1 << 22
+    with R.FftMagCfarChainVanilla(params) as dut:
+        dut.configure(rt)
+        d_in = R.DeviceBuffer(beats.nbytes); d_in.upload(beats)
+        d_out = R.DeviceBuffer(beats.size * 4)
+        d_list, d_cnt = R.DeviceBuffer(cap * 16), R.DeviceBuffer(8)
+        dut.process_detect_device(d_in.ptr, frames, d_out.ptr, d_list.ptr, cap, d_cnt.ptr)
+        dut.synchronize()
+        dense = d_out.download(np.uint32, beats.size).reshape(frames, n)
+        found, stored = (int(v) for v in d_cnt.download(np.uint32, 2))
+        lst = d_list.download(np.uint32, stored * 4).reshape(stored, 4)
+    fr, bn = np.nonzero(dense & 1)
+    assert found == stored == fr.size and fr.size > frames
+    key = lst[:, 0].astype(np.int64) * n + lst[:, 1]
+    if frames <= 16384:
+        assert np.array_equal(lst[:, 0], fr)                                         # frames already in order
+    else:
+        assert np.array_equal(np.sort(key), fr.astype(np.int64) * n + bn)
+    assert np.array_equal(np.sort(key), fr.astype(np.int64) * n + bn)
+    assert np.array_equal(lst[np.argsort(key), 3], dense[fr, bn])

@@ -8,15 +8,20 @@ nr = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 nd = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 n_ch = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+fixed = os.environ.get("RSP_PROF_FIXED") == "1"     # FIXED16 data path (int16 I/Q beats)
 params = R.FftMagCfarVanillaParameters(
     fftParams=R.FFTParams.fixed(numPoints=nr), magParams=R.MAGParams.fixed(),
-    cfarParams=R.CFARParams(fftSize=nr, leadLaggWindowSize=16), dtype=R.F32, dopplerPoints=nd, refDoppler=8, guardDoppler=2)
-rt = R.RunTimeRspChainParams(fftSize=nr, CFARMode="Cell Averaging", refWindowSize=8, guardWindowSize=2, divSum=4, thresholdScaler=4.0)
+    cfarParams=R.CFARParams(fftSize=nr, leadLaggWindowSize=16), dtype=R.FIXED16 if fixed else R.F32, dopplerPoints=nd,
+    refDoppler=8, guardDoppler=2)
+rt = R.RunTimeRspChainParams(fftSize=nr, CFARMode="Cell Averaging", refWindowSize=8, guardWindowSize=2, divSum=8 if fixed else 4,
+                             thresholdScaler=4.0)
 dut = R.FftMagCfarChainVanilla(params); dut.configure(rt)
 if os.environ.get("RSP_RD_CHUNK_MB") is not None: dut.set_option(dut.RD_CHUNK_BYTES, int(os.environ["RSP_RD_CHUNK_MB"]) << 20)
 rng = np.random.default_rng(2345)
 x = (0.05 * (rng.standard_normal((nd, nr)) + 1j * rng.standard_normal((nd, nr)))).astype(np.complex64)
 x = np.tile(x, (n_ch, 1, 1))
+if fixed:
+    x = ((np.rint(x.real * 2e4).astype(np.int64) & 0xffff) << 16 | (np.rint(x.imag * 2e4).astype(np.int64) & 0xffff)).astype(np.uint32)
 sets = 3
 ins, outs = [], []
 for s in range(sets):
