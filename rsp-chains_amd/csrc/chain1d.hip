@@ -1293,6 +1293,12 @@ compact_frames_kernel(const uint32_t* __restrict__ fcount, const uint2* __restri
   __shared__ uint32_t ovf_frame[256], ovf_base[256];
   const uint32_t f = blockIdx.x * 256 + threadIdx.x;
   const uint32_t found = f < n_frames ? fcount[f] : 0u;
+  u32x4 early[8];  // slots 0..15 of the frame, requested before the count is known (stale slots are never used)
+  {
+    const u32x4* src = reinterpret_cast<const u32x4*>(fdet + (size_t)(f < n_frames ? f : 0) * kFrameDetCap);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) early[j] = src[j];
+  }
   // a frame whose peaks did not fit its slots is re-read from the dense words when there are any
   const bool ovf = found > (uint32_t)kFrameDetCap;
   const uint32_t mine = (ovf && !words) ? (uint32_t)kFrameDetCap : found;
@@ -1353,10 +1359,9 @@ compact_frames_kernel(const uint32_t* __restrict__ fcount, const uint2* __restri
     ovf_frame[s] = f;
     ovf_base[s] = base;
   } else {
-    // four slots (two 16-byte loads) per round: the rounds' loads do not wait for each other's stores
-    const u32x4* src = reinterpret_cast<const u32x4*>(fdet + (size_t)f * kFrameDetCap);
-    for (uint32_t i = 0; i < mine; i += 4) {
-      const u32x4 e01 = src[i / 2], e23 = (i + 2 < mine) ? src[i / 2 + 1] : u32x4{0u, 0u, 0u, 0u};
+    // the first 16 slots were requested together with the count (one memory round trip for all but ~1e-4 of the
+    // frames at 5 peaks per frame); later slots four per round (two 16-byte loads)
+    auto put = [&](uint32_t i, const u32x4& e01, const u32x4& e23) {
       const uint32_t bins[4] = {e01.x, e01.z, e23.x, e23.z}, wds[4] = {e01.y, e01.w, e23.y, e23.w};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -1369,7 +1374,12 @@ compact_frames_kernel(const uint32_t* __restrict__ fcount, const uint2* __restri
           list[base + i + q] = d;
         }
       }
-    }
+    };
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (4u * r < mine) put(4u * r, early[2 * r], early[2 * r + 1]);
+    const u32x4* src = reinterpret_cast<const u32x4*>(fdet + (size_t)f * kFrameDetCap);
+    for (uint32_t i = 16; i < mine; i += 4) put(i, src[i / 2], (i + 2 < mine) ? src[i / 2 + 1] : u32x4{0u, 0u, 0u, 0u});
   }
   __syncthreads();
   // overflow frames (rare: > kFrameDetCap peaks in one frame): the whole workgroup re-reads the frame
