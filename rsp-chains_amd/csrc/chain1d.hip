@@ -943,6 +943,20 @@ template <typename V> __device__ __forceinline__ V vmax(V a, V b) { return a > b
 // infinity is the same selection in ONE instruction (the infinities sit in SGPRs)
 template <> __device__ __forceinline__ float vmin<float>(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, -__builtin_inff()); }
 template <> __device__ __forceinline__ float vmax<float>(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
+// the same for the selection network, where the compiler folds the med3-with-infinity back into v_min / v_max and
+// canonicalises both operands first (3 instructions per selection): the bare instruction
+template <typename V> __device__ __forceinline__ V vmin1(V a, V b) { return a < b ? a : b; }
+template <typename V> __device__ __forceinline__ V vmax1(V a, V b) { return a > b ? a : b; }
+template <> __device__ __forceinline__ float vmin1<float>(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+template <> __device__ __forceinline__ float vmax1<float>(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 // median of three, a <= c guaranteed by the caller
 template <typename V> __device__ __forceinline__ V vmed3(V a, V b, V c) { return vmin(vmax(a, b), c); }
 template <> __device__ __forceinline__ float vmed3<float>(float a, float b, float c) {
@@ -1024,6 +1038,9 @@ __device__ __forceinline__ void slide(typename WinVec<V, R>::type& s, V old, V n
   s[R - 1] = vmax(t[R - 2], nw);
 }
 
+#ifndef RSP_GOS_SPLIT
+#define RSP_GOS_SPLIT 1
+#endif
 struct GosLayout {  // byte offsets inside a frame's LDS, computed on the host
   int32_t frame_bytes, o1_off, o2_off, det_off, run;  // run = consecutive window starts per thread
 };
@@ -1048,7 +1065,69 @@ __device__ __forceinline__ void gos_stage(const V* mag, V* o1, V* o2, int tau, i
   }
 }
 
-template <int M, bool FIXED>
+// k-th smallest (0-based, wave-uniform k) of a bitonic sequence of SZ = 2^n values: a half-cleaner per level leaves
+// the SZ/2 smallest (min side) or largest (max side) as a bitonic sequence again, so only the side that holds rank k
+// is computed: SZ - 1 min / max operations in all, every index a compile-time constant, the side a scalar branch.
+template <int SZ, typename V>
+__device__ __forceinline__ V select_bitonic(const V (&x)[SZ], int k) {
+  if constexpr (SZ == 1) {
+    return x[0];
+  } else {
+    V h[SZ / 2];
+    if (k & (SZ / 2)) {
+#pragma unroll
+      for (int i = 0; i < SZ / 2; ++i) h[i] = vmax1(x[i], x[i + SZ / 2]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < SZ / 2; ++i) h[i] = vmin1(x[i], x[i + SZ / 2]);
+    }
+    return select_bitonic<SZ / 2, V>(h, k);
+  }
+}
+
+// The same statistics with the window SPLIT: the RUN windows of a thread (starts a0 .. a0 + RUN - 1) all contain
+// the cells B = [a0 + RUN - 1, a0 + R); only the other RUN - 1 cells D change from start to start (one leaves at
+// the front, one enters past B).  B is sorted once, D is kept sorted with the delete + insert slide -- 3 (RUN - 1)
+// operations per start instead of 3 R -- and the order statistic is selected from the bitonic sequence
+// [B ascending | D descending] with R - 1 min / max.  R = 32, RUN = 17: two 16-element sorts + 16 x 48 + 17 x 31 =
+// 1547 operations per 17 starts against 382 + 16 x 94 = 1886 with one 32-cell sorted window.
+template <typename V, int R, int RUN>
+__device__ __forceinline__ void gos_stage_split(const V* mag, V* o1, V* o2, int tau, int G, int idx_lagg, int idx_lead) {
+  constexpr int ND = RUN - 1, NB = R - ND;
+  static_assert(NB >= 1 && (R & (R - 1)) == 0, "a common part and a power-of-two window");
+  const int a0 = -(G + R) + RUN * tau;  // first window start of this thread
+  typename WinVec<V, ND>::type d;
+  typename WinVec<V, NB>::type b;
+#pragma unroll
+  for (int i = 0; i < ND; ++i) d[i] = mag[pad(a0 + i + kHalo)];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) b[i] = mag[pad(a0 + ND + i + kHalo)];
+  sort_window<V, ND>(d);
+  sort_window<V, NB>(b);
+  const bool two = idx_lagg != idx_lead;
+#pragma unroll 1
+  for (int st = 0; st < RUN; ++st) {
+    V seq[R];  // [B ascending | D descending]
+#pragma unroll
+    for (int i = 0; i < NB; ++i) seq[i] = b[i];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) seq[NB + i] = d[ND - 1 - i];
+    int k1 = idx_lagg, k2 = idx_lead;
+    asm volatile("" : "+s"(k1), "+s"(k2));  // keep the five side branches inside the loop (no 32-way unswitching)
+    const int oi = pad(RUN * tau + st);
+    o1[oi] = select_bitonic<R, V>(seq, k1);
+    if (two) o2[oi] = select_bitonic<R, V>(seq, k2);
+    if (st + 1 < RUN) {
+      const V old = mag[pad(a0 + st + kHalo)], nw = mag[pad(a0 + st + R + kHalo)];
+      slide<V, ND>(d, old, nw);
+    }
+  }
+}
+
+// BIG = the 64-cell window: its sorted window alone is 64 + 63 registers, so it is a kernel of its own -- as one path
+// of a common kernel it set the register count (141 + scratch) and with it the occupancy (one 512-thread workgroup
+// per CU at 8192 points) of every other window size.
+template <int M, bool FIXED, bool BIG>
 __global__ void __launch_bounds__(wg_size(M))
 chain1d_gos_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t n_frames,
                    ChainRegs rg, GosLayout lay, const void* __restrict__ tw,
@@ -1086,12 +1165,19 @@ chain1d_gos_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint
     if (h == 31) mag[pad(N + kHalo + kHalo)] = wrap ? mag[pad(kHalo + kHalo)] : V(0);
   }
   __syncthreads();
-  switch (rg.R) {
-    case 4: gos_stage<V, 4>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead); break;
-    case 8: gos_stage<V, 8>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead); break;
-    case 16: gos_stage<V, 16>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead); break;
-    case 32: gos_stage<V, 32>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead); break;
-    default: gos_stage<V, 64>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead); break;
+  if constexpr (BIG) {
+    if (lay.run == 17 && RSP_GOS_SPLIT) gos_stage_split<V, 64, 17>(mag, o1, o2, tau, rg.G, rg.idx_lagg, rg.idx_lead);
+    else gos_stage<V, 64>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead);
+  } else {
+    switch (rg.R) {
+      case 4: gos_stage<V, 4>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead); break;
+      case 8: gos_stage<V, 8>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead); break;
+      case 16: gos_stage<V, 16>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead); break;
+      default:
+        if (lay.run == 17 && RSP_GOS_SPLIT) gos_stage_split<V, 32, 17>(mag, o1, o2, tau, rg.G, rg.idx_lagg, rg.idx_lead);
+        else gos_stage<V, 32>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead);
+        break;
+    }
   }
   __syncthreads();
 
@@ -1145,21 +1231,19 @@ static hipError_t launch_gos(const Chain1dLaunch& a) {
   const GosLayout lay = gos_layout<M>(a.regs);
   const size_t lds = (size_t)lay.frame_bytes * fpw + (a.fixed ? FrameLds<M>::ROM_BYTES : 0);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  static LdsGrant granted[2];
   hipError_t e;
-  if (a.fixed) {
-    auto k = chain1d_gos_kernel<M, true>;
-    e = grant_lds(k, lds, a.device, granted[0]);
-    if (e != hipSuccess) return e;
+  auto go = [&](auto k, LdsGrant& g) -> hipError_t {
+    hipError_t err = grant_lds(k, lds, a.device, g);
+    if (err != hipSuccess) return err;
     hipLaunchKernelGGL(k, dim3(grid), dim3(wg_size(M)), lds, a.stream, a.in, a.out, a.n_frames, a.regs, lay,
                        a.twiddles, a.log_lut, a.frame_count, a.frame_det);
-  } else {
-    auto k = chain1d_gos_kernel<M, false>;
-    e = grant_lds(k, lds, a.device, granted[1]);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(wg_size(M)), lds, a.stream, a.in, a.out, a.n_frames, a.regs, lay,
-                       a.twiddles, a.log_lut, a.frame_count, a.frame_det);
-  }
+    return hipSuccess;
+  };
+  static LdsGrant g4[4];
+  const bool big = a.regs.R > 32;
+  if (a.fixed) e = big ? go(chain1d_gos_kernel<M, true, true>, g4[0]) : go(chain1d_gos_kernel<M, true, false>, g4[1]);
+  else e = big ? go(chain1d_gos_kernel<M, false, true>, g4[2]) : go(chain1d_gos_kernel<M, false, false>, g4[3]);
+  if (e != hipSuccess) return e;
   return hipGetLastError();
 }
 
