@@ -75,6 +75,7 @@ struct FrameLds {
 __device__ __forceinline__ int mag_slot(int x) { return pad(x + 16); }
 __device__ __forceinline__ int pb_slot(int x) { return pad(x + kHalo); }
 
+#ifndef RSP_PART_FX
 size_t chain1d_lds_bytes(int log2n) {
   switch (log2n) {
     case 8: return FrameLds<8>::BYTES * frames_per_wg(8);
@@ -86,6 +87,7 @@ size_t chain1d_lds_bytes(int log2n) {
     default: return 0;
   }
 }
+#endif
 
 // ---------------------------------------------------------------- magnitude (logMagMux)
 
@@ -113,7 +115,7 @@ __device__ __forceinline__ V row_shr(V v) {
 // ---------------------------------------------------------------- shared front end
 // Frame -> FFT (passes through LDS at fbase) -> magnitude of this thread's 16 bins in registers:
 // mg[g * 2^WL + p] is bin (bitrev(p) << (M - WL)) | bitrev(g T + tau).
-template <int M, bool FIXED, typename V>
+template <int M, bool FIXED, typename V, int FX = -1>
 __device__ __forceinline__ void front_end(const void* __restrict__ in, uint32_t frame, bool live, int tau,
                                           unsigned char* fbase, const ChainRegs& rg,
                                           const void* __restrict__ tw,
@@ -249,7 +251,7 @@ __device__ __forceinline__ void front_end(const void* __restrict__ in, uint32_t 
     // twiddle ROM -> LDS once per workgroup (the sample loads above are already in flight)
     for (int i = threadIdx.x; i < N / 2; i += wg_size(M)) rom[i] = twq[i];
     __syncthreads();
-    fft_fx_frame<M>(xr, xi, tau, fbase, rom, rg);
+    fft_fx_frame<M, FX>(xr, xi, tau, fbase, rom, rg);
     if (rg.mag_mode == 2) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) mg[e] = jpl_fx(xr[e], xi[e]);
@@ -335,7 +337,7 @@ __device__ __forceinline__ void emit_words(const uint32_t (&word)[16], uint32_t*
   }
 }
 
-template <int M, bool FIXED>
+template <int M, bool FIXED, int FX>
 __global__ void __launch_bounds__(wg_size(M))
 chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t n_frames,
                ChainRegs rg, const void* __restrict__ tw, const int16_t* __restrict__ log_lut,
@@ -353,7 +355,7 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
 
   V mg[16];
   STAMP_DECL;
-  front_end<M, FIXED, V>(in, frame, live, tau, fbase, rg, tw, log_lut,
+  front_end<M, FIXED, V, FX>(in, frame, live, tau, fbase, rg, tw, log_lut,
                          reinterpret_cast<uint32_t*>(smem + (size_t)L::BYTES * FPW), mg STAMP_ARG);
 
   // ---- magnitudes to LDS in natural bin order ----
@@ -613,7 +615,7 @@ __device__ __forceinline__ V seg_scan(V v) {
   return v;
 }
 
-template <int M, bool FIXED>
+template <int M, bool FIXED, int FX>
 __global__ void __launch_bounds__(wg_size(M))
 chain1d_quad_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t n_frames,
                     ChainRegs rg, const void* __restrict__ tw, const int16_t* __restrict__ log_lut,
@@ -635,7 +637,7 @@ chain1d_quad_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uin
   V mg[16];
   STAMP_DECL;
   STAMP(0);
-  front_end<M, FIXED, V>(in, frame, live, tau, fbase, rg, tw, log_lut,
+  front_end<M, FIXED, V, FX>(in, frame, live, tau, fbase, rg, tw, log_lut,
                          reinterpret_cast<uint32_t*>(smem + (size_t)L::BYTES * FPW), mg STAMP_ARG);
   STAMP(7);
 
@@ -1127,7 +1129,7 @@ __device__ __forceinline__ void gos_stage_split(const V* mag, V* o1, V* o2, int 
 // BIG = the 64-cell window: its sorted window alone is 64 + 63 registers, so it is a kernel of its own -- as one path
 // of a common kernel it set the register count (141 + scratch) and with it the occupancy (one 512-thread workgroup
 // per CU at 8192 points) of every other window size.
-template <int M, bool FIXED, bool BIG>
+template <int M, bool FIXED, bool BIG, int FX>
 __global__ void __launch_bounds__(wg_size(M))
 chain1d_gos_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t n_frames,
                    ChainRegs rg, GosLayout lay, const void* __restrict__ tw,
@@ -1144,7 +1146,7 @@ chain1d_gos_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint
 
   V mg[16];
   STAMP_DECL;
-  front_end<M, FIXED, V>(in, frame, live, tau, fbase, rg, tw, log_lut,
+  front_end<M, FIXED, V, FX>(in, frame, live, tau, fbase, rg, tw, log_lut,
                          reinterpret_cast<uint32_t*>(smem + (size_t)lay.frame_bytes * FPW), mg STAMP_ARG);
 
   V* mag = reinterpret_cast<V*>(fbase);  // cell x in [-256, N + 256] at slot pad(x + 256)
@@ -1224,49 +1226,69 @@ static GosLayout gos_layout(const ChainRegs& rg) {
   return l;
 }
 
+// This file is compiled twice (csrc/Makefile): once for the fp32 kernels and once, with RSP_PART_FX, for the FIXED16
+// ones -- two objects built in parallel instead of one 4-minute compile, and every kernel is instantiated for ONE
+// path of the fixed-point FFT (FX, fft_lds.hpp) so that no configuration carries another one's registers.
+#ifdef RSP_PART_FX
+constexpr bool kPartFixed = true;
+#else
+constexpr bool kPartFixed = false;
+#endif
+// FX of a launch: 0 convergent, 1 floor / half-up, 2 stage options (fp32: always 0)
+static int fx_mode(const Chain1dLaunch& a) {
+  if (!kPartFixed) return 0;
+  return (a.regs.keep_lsb_mask | a.regs.expand_mask) ? 2 : (a.regs.trim_conv ? 0 : 1);
+}
+// calls f(std::integral_constant<int, FX>) for the launch's FX; only FX = 0 exists in the fp32 object
+template <typename F>
+static hipError_t with_fx(const Chain1dLaunch& a, F f) {
+  if constexpr (kPartFixed) {
+    switch (fx_mode(a)) {
+      case 1: return f(std::integral_constant<int, 1>{});
+      case 2: return f(std::integral_constant<int, 2>{});
+      default: break;
+    }
+  }
+  return f(std::integral_constant<int, 0>{});
+}
+
 template <int M>
 static hipError_t launch_gos(const Chain1dLaunch& a) {
   const uint32_t fpw = frames_per_wg(M);
   const uint32_t grid = (a.n_frames + fpw - 1) / fpw;
   const GosLayout lay = gos_layout<M>(a.regs);
-  const size_t lds = (size_t)lay.frame_bytes * fpw + (a.fixed ? FrameLds<M>::ROM_BYTES : 0);
+  const size_t lds = (size_t)lay.frame_bytes * fpw + (kPartFixed ? FrameLds<M>::ROM_BYTES : 0);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  hipError_t e;
   auto go = [&](auto k, LdsGrant& g) -> hipError_t {
     hipError_t err = grant_lds(k, lds, a.device, g);
     if (err != hipSuccess) return err;
     hipLaunchKernelGGL(k, dim3(grid), dim3(wg_size(M)), lds, a.stream, a.in, a.out, a.n_frames, a.regs, lay,
                        a.twiddles, a.log_lut, a.frame_count, a.frame_det);
-    return hipSuccess;
+    return hipGetLastError();
   };
-  static LdsGrant g4[4];
-  const bool big = a.regs.R > 32;
-  if (a.fixed) e = big ? go(chain1d_gos_kernel<M, true, true>, g4[0]) : go(chain1d_gos_kernel<M, true, false>, g4[1]);
-  else e = big ? go(chain1d_gos_kernel<M, false, true>, g4[2]) : go(chain1d_gos_kernel<M, false, false>, g4[3]);
-  if (e != hipSuccess) return e;
-  return hipGetLastError();
+  return with_fx(a, [&](auto fx) -> hipError_t {
+    constexpr int FX = decltype(fx)::value;
+    static LdsGrant g2[2];
+    return a.regs.R > 32 ? go(chain1d_gos_kernel<M, kPartFixed, true, FX>, g2[0])
+                         : go(chain1d_gos_kernel<M, kPartFixed, false, FX>, g2[1]);
+  });
 }
 
 template <int M>
 static hipError_t launch_quad(const Chain1dLaunch& a) {
   const uint32_t fpw = frames_per_wg(M);
   const uint32_t grid = (a.n_frames + fpw - 1) / fpw;
-  const size_t lds = QuadLds<M>::BYTES * fpw + (a.fixed ? QuadLds<M>::ROM_BYTES : 0);
-  static LdsGrant granted[2];
-  if (a.fixed) {
-    auto k = chain1d_quad_kernel<M, true>;
-    hipError_t e = grant_lds(k, lds, a.device, granted[0]);
+  const size_t lds = QuadLds<M>::BYTES * fpw + (kPartFixed ? QuadLds<M>::ROM_BYTES : 0);
+  return with_fx(a, [&](auto fx) -> hipError_t {
+    constexpr int FX = decltype(fx)::value;
+    static LdsGrant granted;
+    auto k = chain1d_quad_kernel<M, kPartFixed, FX>;
+    hipError_t e = grant_lds(k, lds, a.device, granted);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(wg_size(M)), lds, a.stream, a.in, a.out, a.n_frames,
                        a.regs, a.twiddles, a.log_lut, a.frame_count, a.frame_det);
-  } else {
-    auto k = chain1d_quad_kernel<M, false>;
-    hipError_t e = grant_lds(k, lds, a.device, granted[1]);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(wg_size(M)), lds, a.stream, a.in, a.out, a.n_frames,
-                       a.regs, a.twiddles, a.log_lut, a.frame_count, a.frame_det);
-  }
-  return hipGetLastError();
+    return hipGetLastError();
+  });
 }
 
 template <int M>
@@ -1275,23 +1297,38 @@ static hipError_t launch_m(const Chain1dLaunch& a) {
   if (quad_tail_supports(M, a.regs) && !a.force_generic_tail) return launch_quad<M>(a);
   const uint32_t fpw = frames_per_wg(M);
   const uint32_t grid = (a.n_frames + fpw - 1) / fpw;
-  const size_t lds = FrameLds<M>::BYTES * fpw + (a.fixed ? FrameLds<M>::ROM_BYTES : 0);
-  static LdsGrant granted[2];
-  if (a.fixed) {
-    auto k = chain1d_kernel<M, true>;
-    hipError_t e = grant_lds(k, lds, a.device, granted[0]);
+  const size_t lds = FrameLds<M>::BYTES * fpw + (kPartFixed ? FrameLds<M>::ROM_BYTES : 0);
+  return with_fx(a, [&](auto fx) -> hipError_t {
+    constexpr int FX = decltype(fx)::value;
+    static LdsGrant granted;
+    auto k = chain1d_kernel<M, kPartFixed, FX>;
+    hipError_t e = grant_lds(k, lds, a.device, granted);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(wg_size(M)), lds, a.stream, a.in, a.out, a.n_frames,
                        a.regs, a.twiddles, a.log_lut, a.frame_count, a.frame_det);
-  } else {
-    auto k = chain1d_kernel<M, false>;
-    hipError_t e = grant_lds(k, lds, a.device, granted[1]);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(wg_size(M)), lds, a.stream, a.in, a.out, a.n_frames,
-                       a.regs, a.twiddles, a.log_lut, a.frame_count, a.frame_det);
-  }
-  return hipGetLastError();
+    return hipGetLastError();
+  });
 }
+
+// one launch (< 4 GiB of input) of this object's data type
+#ifdef RSP_PART_FX
+hipError_t launch_chain1d_part_fx(const Chain1dLaunch& a) {
+#else
+hipError_t launch_chain1d_part_f32(const Chain1dLaunch& a) {
+#endif
+  switch (a.log2n) {
+    case 8: return launch_m<8>(a);
+    case 9: return launch_m<9>(a);
+    case 10: return launch_m<10>(a);
+    case 11: return launch_m<11>(a);
+    case 12: return launch_m<12>(a);
+    case 13: return launch_m<13>(a);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+#ifndef RSP_PART_FX  // everything below is data-type independent: compiled once
+hipError_t launch_chain1d_part_fx(const Chain1dLaunch& a);
 
 hipError_t launch_chain1d(const Chain1dLaunch& a0) {
   if (a0.n_frames == 0) return hipSuccess;
@@ -1310,16 +1347,7 @@ hipError_t launch_chain1d(const Chain1dLaunch& a0) {
     a.out = a0.out ? a0.out + (((uint64_t)done << a0.log2n) << (a0.regs.send_cut ? 1 : 0)) : nullptr;
     a.frame_count = a0.frame_count ? a0.frame_count + done : nullptr;
     a.frame_det = a0.frame_det ? a0.frame_det + (uint64_t)done * kFrameDetCap : nullptr;
-    hipError_t e;
-    switch (a.log2n) {
-      case 8: e = launch_m<8>(a); break;
-      case 9: e = launch_m<9>(a); break;
-      case 10: e = launch_m<10>(a); break;
-      case 11: e = launch_m<11>(a); break;
-      case 12: e = launch_m<12>(a); break;
-      case 13: e = launch_m<13>(a); break;
-      default: return hipErrorInvalidValue;
-    }
+    const hipError_t e = a.fixed ? launch_chain1d_part_fx(a) : launch_chain1d_part_f32(a);
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
@@ -1603,5 +1631,7 @@ hipError_t launch_compact(const uint32_t* words, uint64_t n_cells, uint32_t log2
   hipLaunchKernelGGL(compact_finalize_kernel, dim3(1), dim3(1), 0, stream, counters, cap, d_count, false);
   return hipGetLastError();
 }
+
+#endif  // RSP_PART_FX
 
 }  // namespace rsp

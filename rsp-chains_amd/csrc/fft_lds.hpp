@@ -462,7 +462,10 @@ __device__ __forceinline__ void pass_fx_opt(int (&xr)[16], int (&xi)[16], int ta
 // Whole FIXED16 FFT of one frame through the LDS image at fbase (4-byte slots {re[31:16], im[15:0]}; 8-byte slots when
 // a stage option grows the word), twiddle ROM already in LDS at rom.  xr / xi hold the thread's 16 samples (first
 // sample first_sample(tau), offsets sample_offset(e)) on entry and its 16 bins on return, as fft_f32_frame.
-template <int M>
+// FX selects the path at compile time -- 0: convergent trim (3-op closed form), 1: floor / half-up, 2: stage options;
+// -1: by the register snapshot at run time.  One kernel holding all three paths carries the registers of the widest
+// (the stage-option path: 180 VGPRs against 77-140 for the others), i.e. half the occupancy for every configuration.
+template <int M, int FX = -1>
 __device__ __forceinline__ void fft_fx_frame(int (&xr)[16], int (&xi)[16], int tau, unsigned char* fbase,
                                              const uint32_t* rom, const ChainRegs& rg) {
   constexpr int NP = plan_np(M);
@@ -543,7 +546,10 @@ __device__ __forceinline__ void fft_fx_frame(int (&xr)[16], int (&xi)[16], int t
     }
   };
   // convergent (the default trim) has a 3-op closed form; floor / half-up share the generic one
-  if (rg.keep_lsb_mask | rg.expand_mask) run_opt();
+  if constexpr (FX == 0) run(std::true_type{});
+  else if constexpr (FX == 1) run(std::false_type{});
+  else if constexpr (FX == 2) run_opt();
+  else if (rg.keep_lsb_mask | rg.expand_mask) run_opt();
   else if (rg.trim_conv) run(std::true_type{});
   else run(std::false_type{});
 }
