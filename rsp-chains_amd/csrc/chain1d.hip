@@ -1226,31 +1226,19 @@ static GosLayout gos_layout(const ChainRegs& rg) {
   return l;
 }
 
-// This file is compiled twice (csrc/Makefile): once for the fp32 kernels and once, with RSP_PART_FX, for the FIXED16
-// ones -- two objects built in parallel instead of one 4-minute compile, and every kernel is instantiated for ONE
-// path of the fixed-point FFT (FX, fft_lds.hpp) so that no configuration carries another one's registers.
+// This file is compiled FOUR times (csrc/Makefile): the fp32 kernels, and -- with RSP_PART_FX = 0 / 1 / 2 -- the
+// FIXED16 kernels of ONE path of the fixed-point FFT each (FX, fft_lds.hpp: 0 convergent, 1 floor / half-up,
+// 2 stage options): four objects built in parallel instead of one 4-minute compile, and no configuration carries
+// another path's registers.
 #ifdef RSP_PART_FX
 constexpr bool kPartFixed = true;
+constexpr int kPartFx = RSP_PART_FX;
 #else
 constexpr bool kPartFixed = false;
+constexpr int kPartFx = 0;
 #endif
-// FX of a launch: 0 convergent, 1 floor / half-up, 2 stage options (fp32: always 0)
-static int fx_mode(const Chain1dLaunch& a) {
-  if (!kPartFixed) return 0;
-  return (a.regs.keep_lsb_mask | a.regs.expand_mask) ? 2 : (a.regs.trim_conv ? 0 : 1);
-}
-// calls f(std::integral_constant<int, FX>) for the launch's FX; only FX = 0 exists in the fp32 object
 template <typename F>
-static hipError_t with_fx(const Chain1dLaunch& a, F f) {
-  if constexpr (kPartFixed) {
-    switch (fx_mode(a)) {
-      case 1: return f(std::integral_constant<int, 1>{});
-      case 2: return f(std::integral_constant<int, 2>{});
-      default: break;
-    }
-  }
-  return f(std::integral_constant<int, 0>{});
-}
+static hipError_t with_fx(const Chain1dLaunch&, F f) { return f(std::integral_constant<int, kPartFx>{}); }
 
 template <int M>
 static hipError_t launch_gos(const Chain1dLaunch& a) {
@@ -1310,9 +1298,11 @@ static hipError_t launch_m(const Chain1dLaunch& a) {
   });
 }
 
-// one launch (< 4 GiB of input) of this object's data type
+// one launch (< 4 GiB of input) of this object's data type / FFT path
+#define RSP_CAT2(a, b) a##b
+#define RSP_CAT(a, b) RSP_CAT2(a, b)
 #ifdef RSP_PART_FX
-hipError_t launch_chain1d_part_fx(const Chain1dLaunch& a) {
+hipError_t RSP_CAT(launch_chain1d_part_fx, RSP_PART_FX)(const Chain1dLaunch& a) {
 #else
 hipError_t launch_chain1d_part_f32(const Chain1dLaunch& a) {
 #endif
@@ -1328,7 +1318,13 @@ hipError_t launch_chain1d_part_f32(const Chain1dLaunch& a) {
 }
 
 #ifndef RSP_PART_FX  // everything below is data-type independent: compiled once
-hipError_t launch_chain1d_part_fx(const Chain1dLaunch& a);
+hipError_t launch_chain1d_part_fx0(const Chain1dLaunch& a);
+hipError_t launch_chain1d_part_fx1(const Chain1dLaunch& a);
+hipError_t launch_chain1d_part_fx2(const Chain1dLaunch& a);
+static hipError_t launch_chain1d_part_fx(const Chain1dLaunch& a) {
+  if (a.regs.keep_lsb_mask | a.regs.expand_mask) return launch_chain1d_part_fx2(a);
+  return a.regs.trim_conv ? launch_chain1d_part_fx0(a) : launch_chain1d_part_fx1(a);
+}
 
 hipError_t launch_chain1d(const Chain1dLaunch& a0) {
   if (a0.n_frames == 0) return hipSuccess;
