@@ -52,9 +52,11 @@ static inline uint32_t rd_tile(int log2nr) {
 }
 
 // ---------------------------------------------------------------- range pass (rows)
-template <int M>
+// TILED is a template parameter: with the row-major layout the 16 stores of a thread are base + compile-time offsets
+// again (a run-time element step cost 7 us of address arithmetic per 16.7 M cells)
+template <int M, bool TILED>
 __global__ void __launch_bounds__(wg_size(M))
-range_fft_kernel(const f32x2* __restrict__ in, f32x2* __restrict__ out, uint32_t n_rows, uint32_t nd, uint32_t tile,
+range_fft_kernel(const f32x2* __restrict__ in, f32x2* __restrict__ out, uint32_t n_rows, uint32_t log2nd,
                  const f32x2* __restrict__ tw, const float* __restrict__ win, uint32_t* __restrict__ zero_count) {
   constexpr int N = 1 << M, T = threads_per_frame(M), FPW = frames_per_wg(M);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -76,16 +78,24 @@ range_fft_kernel(const f32x2* __restrict__ in, f32x2* __restrict__ out, uint32_t
   constexpr int NP = plan_np(M), WL = plan_w(M, NP - 1);
   const float scale = 1.0f / (float)N;
   if (!live) return;
-  // bins c + tau with c a multiple of T >= 16: the tile index splits into a per-lane and a per-register part
-  static_assert(T % kTileCols == 0, "a register's bins start on a tile boundary");
-  const uint32_t ch = row / nd, d = row % nd;
-  f32x2* dst = out + (size_t)ch * nd * N + map_index(d, tau, nd, N, tile);
-  const size_t step = tile ? (size_t)nd : 1;  // elements between bins c and c + 1 tile-columns apart, per bin
+  if constexpr (!TILED) {
+    f32x2* dst = out + (size_t)row * N + tau;
 #pragma unroll
-  for (int g = 0; g < (16 >> WL); ++g) {
+    for (int g = 0; g < (16 >> WL); ++g) {
 #pragma unroll
-    for (int p = 0; p < (1 << WL); ++p)
-      dst[(size_t)((bitrev_c(p, WL) << (M - WL)) + g * T) * step] = x[g * (1 << WL) + p] * scale;
+      for (int p = 0; p < (1 << WL); ++p) dst[(bitrev_c(p, WL) << (M - WL)) + g * T] = x[g * (1 << WL) + p] * scale;
+    }
+  } else {
+    // bins c + tau with c a multiple of T >= 16: the tile index splits into a per-lane and a per-register part
+    static_assert(T % kTileCols == 0, "a register's bins start on a tile boundary");
+    const uint32_t nd = 1u << log2nd, ch = row >> log2nd, d = row & (nd - 1);
+    f32x2* dst = out + (((size_t)ch << log2nd) << M) + map_index(d, tau, nd, N, kTileCols);
+#pragma unroll
+    for (int g = 0; g < (16 >> WL); ++g) {
+#pragma unroll
+      for (int p = 0; p < (1 << WL); ++p)
+        dst[(size_t)((bitrev_c(p, WL) << (M - WL)) + g * T) << log2nd] = x[g * (1 << WL) + p] * scale;
+    }
   }
 }
 
@@ -707,16 +717,18 @@ cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, ui
 // ---------------------------------------------------------------- launchers
 
 template <int M>
-static hipError_t launch_range_m(const f32x2* in, f32x2* out, uint32_t n_rows, uint32_t nd, uint32_t tile, const f32x2* tw, const float* win, uint32_t* zero_count,
+static hipError_t launch_range_m(const f32x2* in, f32x2* out, uint32_t n_rows, int log2nd, uint32_t tile, const f32x2* tw, const float* win, uint32_t* zero_count,
                                  hipStream_t s, int device) {
-  const uint32_t fpw = frames_per_wg(M);
-  const size_t lds = (size_t)8 * fft_image_slots(M) * fpw;
-  auto k = range_fft_kernel<M>;
-  static LdsGrant granted;
-  hipError_t e = grant_lds(k, lds, device, granted);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k, dim3((n_rows + fpw - 1) / fpw), dim3(wg_size(M)), lds, s, in, out, n_rows, nd, tile, tw, win, zero_count);
-  return hipGetLastError();
+  constexpr int fpw = frames_per_wg(M);
+  const size_t lds = (size_t)fpw * fft_image_slots(M) * sizeof(f32x2);
+  auto go = [&](auto k, LdsGrant& granted) -> hipError_t {
+    hipError_t e = grant_lds(k, lds, device, granted);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3((n_rows + fpw - 1) / fpw), dim3(wg_size(M)), lds, s, in, out, n_rows, (uint32_t)log2nd, tw, win, zero_count);
+    return hipGetLastError();
+  };
+  static LdsGrant g2[2];
+  return tile ? go(range_fft_kernel<M, true>, g2[0]) : go(range_fft_kernel<M, false>, g2[1]);
 }
 
 template <int MD>
@@ -748,12 +760,12 @@ static hipError_t launch_rd2d_chunk(const Rd2dLaunch& a, uint32_t ch0, uint32_t 
   const uint32_t rows = n_ch * nd, tile = rd_tile(a.log2nr);
   uint32_t* zero_count = (a.det_list && ch0 == 0) ? a.det_count : nullptr;  // first chunk of the batch
   switch (a.log2nr) {
-    case 8: e = launch_range_m<8>(in, x1, rows, nd, tile, twr, wr, zero_count, a.stream, a.device); break;
-    case 9: e = launch_range_m<9>(in, x1, rows, nd, tile, twr, wr, zero_count, a.stream, a.device); break;
-    case 10: e = launch_range_m<10>(in, x1, rows, nd, tile, twr, wr, zero_count, a.stream, a.device); break;
-    case 11: e = launch_range_m<11>(in, x1, rows, nd, tile, twr, wr, zero_count, a.stream, a.device); break;
-    case 12: e = launch_range_m<12>(in, x1, rows, nd, tile, twr, wr, zero_count, a.stream, a.device); break;
-    case 13: e = launch_range_m<13>(in, x1, rows, nd, tile, twr, wr, zero_count, a.stream, a.device); break;
+    case 8: e = launch_range_m<8>(in, x1, rows, a.log2nd, tile, twr, wr, zero_count, a.stream, a.device); break;
+    case 9: e = launch_range_m<9>(in, x1, rows, a.log2nd, tile, twr, wr, zero_count, a.stream, a.device); break;
+    case 10: e = launch_range_m<10>(in, x1, rows, a.log2nd, tile, twr, wr, zero_count, a.stream, a.device); break;
+    case 11: e = launch_range_m<11>(in, x1, rows, a.log2nd, tile, twr, wr, zero_count, a.stream, a.device); break;
+    case 12: e = launch_range_m<12>(in, x1, rows, a.log2nd, tile, twr, wr, zero_count, a.stream, a.device); break;
+    case 13: e = launch_range_m<13>(in, x1, rows, a.log2nd, tile, twr, wr, zero_count, a.stream, a.device); break;
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
@@ -772,9 +784,12 @@ static hipError_t launch_rd2d_chunk(const Rd2dLaunch& a, uint32_t ch0, uint32_t 
   const bool spec = a.regs.R == 8 && a.regs.G == 2 && a.ref_d == 8 && a.guard_d == 2;  // cfg 3 / cfg 5
   if (spec && !a.force_tiled_cfar) {
     const uint32_t strips = (nr + walk_outw(10) - 1) / walk_outw(10);
-    // rows per wave: every segment re-reads 2 HD + 1 = 21 halo rows, so 64 rows cost 1.33x the map in reads, 128 rows 1.16x
+    // rows per wave.  Every segment reads 2 HD halo rows beside its own, but with the waves of a workgroup walking
+    // towards / away from each other those are L2 hits (8.07 B/cell of HBM traffic at 64 rows): the choice is about
+    // parallelism and latency.  32 rows: 29 us at 8 x 4096 x 512 (same as 64), 137 against 150 us at 8 x 8192 x 1024;
+    // 128 rows: 35 / 148 us.
 #ifndef RSP_WALK_SEG
-#define RSP_WALK_SEG 64
+#define RSP_WALK_SEG 32
 #endif
     constexpr uint32_t SEG = RSP_WALK_SEG;
     const dim3 grid(n_ch * strips * (nd / SEG / 4));
