@@ -110,8 +110,12 @@ range_fft_kernel(const f32x2* __restrict__ in, f32x2* __restrict__ out, uint32_t
 #define RSP_DOPPLER_XCDMAP (C * 8 < 128)
 #endif
 constexpr int kColsPerWg(int MD) { return MD >= 10 ? (RSP_DOPPLER_COLS10) : MD == 9 ? (RSP_DOPPLER_COLS9) : 16; }
-// LDS bytes per column: the padded FFT image + 32 B so that adjacent columns start 8 banks apart
-constexpr int kColBytes(int MD) { return 8 * fft_image_slots(MD) + 32; }
+// LDS bytes per column: the padded FFT image + a skew that spreads the columns of a wave over the banks.  The lanes
+// of a ds_write_b64's 16-lane group (ds_read_b64: 32-lane group) are the workgroup's columns at one position, so the
+// column pitch decides the conflicts: with 8 columns, images 8 banks apart (+32 B) are conflict-free; with 16 columns
+// that pitch wraps the banks twice -- 5632 LDS cycles per wave and frame at 512 Doppler bins against 2304 with +8 B
+// (2 banks apart; tools/lds_sim.py model, SQ_LDS_BANK_CONFLICT 12.6 M -> per launch confirmed it).
+constexpr int kColBytes(int MD) { return 8 * fft_image_slots(MD) + (kColsPerWg(MD) >= 16 ? 8 : 32); }
 
 template <int MD>
 __global__ void __launch_bounds__(threads_per_frame(MD) * kColsPerWg(MD))
@@ -211,7 +215,7 @@ range_fx_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uin
 }
 
 constexpr int kFxCols = 16;  // range bins per workgroup of the FIXED16 Doppler pass
-constexpr int kFxColBytes(int MD) { return 4 * fft_image_slots(MD) + 16; }
+constexpr int kFxColBytes(int MD) { return 4 * fft_image_slots(MD) + (MD >= 10 ? 16 : 8); }  // column skew: as kColBytes, for 4-byte slots
 
 template <int MD>
 __global__ void __launch_bounds__(threads_per_frame(MD) * kFxCols)
