@@ -326,3 +326,37 @@ def test_rd2d_fixed_rejects_stage_options(gpu):
     p.fftParams.expandLogic[0] = 1
     with pytest.raises(NotImplementedError):
         R.FftMagCfarChainVanilla(p)
+
+
+@pytest.mark.parametrize("scaler,chunk_mb", [(0.6, 0), (4.0, 1), (0.6, 1)])
+def test_rd2d_fused_list_overflow_and_chunks(gpu, scaler, chunk_mb):
+    """Fused list under stress: a threshold below the noise (tens of thousands of peaks: every wave overflows its
+    LDS staging and re-reads its words) and / or the batch run in chunks of channels that share the scratch maps
+    (only the first chunk's range pass may zero the list's cursor)."""
+    nr, nd, n_ch = 512, 256, 4
+    params = rd_params(nr, nd)
+    rt = R.RunTimeRspChainParams(fftSize=nr, CFARMode="Cell Averaging", refWindowSize=8, guardWindowSize=2, divSum=4,
+                                 thresholdScaler=scaler)
+    x, _ = targets(n_ch, nd, nr, seed=1001)
+    cap = 1 << 20
+    with R.FftMagCfarChainVanilla(params) as dut:
+        dut.configure(rt)
+        if chunk_mb:
+            dut.set_option(dut.RD_CHUNK_BYTES, chunk_mb << 20)    # 1 MiB < one channel's 1.5 MiB of intermediates: 1 channel per chunk
+        d_in = R.DeviceBuffer(x.nbytes); d_in.upload(x)
+        d_out = R.DeviceBuffer(x.size * 4)
+        d_list, d_cnt = R.DeviceBuffer(cap * 16), R.DeviceBuffer(8)
+        for _ in range(2):                                        # twice: the cursor restarts from zero every call
+            dut.process_detect_device(d_in.ptr, n_ch, d_out.ptr, d_list.ptr, cap, d_cnt.ptr)
+        dut.synchronize()
+        dense = d_out.download(np.uint32, x.size).reshape(n_ch, nd, nr)
+        found, stored = (int(v) for v in d_cnt.download(np.uint32, 2))
+        lst = d_list.download(np.uint32, stored * 4).reshape(stored, 4)
+    ch, d, r = np.nonzero(dense & 1)
+    assert found == stored == ch.size
+    if scaler < 1:
+        assert ch.size > 50000
+    key = (lst[:, 0].astype(np.int64) * nd + lst[:, 2]) * nr + lst[:, 1]
+    order = np.argsort(key)
+    assert np.array_equal(key[order], (ch.astype(np.int64) * nd + d) * nr + r)
+    assert np.array_equal(lst[order, 3], dense[ch, d, r])
