@@ -450,31 +450,13 @@ cfar2d_kernel(const T* __restrict__ mag, uint32_t* __restrict__ out, uint32_t nd
 // ring indices are compile-time); the ring's spare slots are rows already in flight from HBM.
 //   vertical:   Vo / Vi = sums over the 2 HD + 1 / 2 GD + 1 rows around the output row, updated by
 //               one add and one subtract per row (registers only);
-//   horizontal: wave-wide inclusive prefix of Vo (Vi) by DPP, window sum = prefix[c + H] -
-//               prefix[c - H - 1] fetched with ds_bpermute (no LDS memory, no barriers).
+//   horizontal: window sums across lanes from runs of 2 / 4 lanes (DPP wave shifts) + ds_bpermute taps (walk_issue /
+//               walk_finish below; no LDS memory, no barriers).
 // Lanes LB .. LE own complete windows: 2 (LE - LB + 1) output columns per strip.
 template <int CTRL, int ROWMASK, bool BOUND>
 __device__ __forceinline__ float dpp_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, BOUND));
 }
-__device__ __forceinline__ float wave_scan_f(float v) {
-  v += dpp_f<0x111, 0xf, true>(v);   // row_shr:1,2,4,8: inclusive scan of each 16-lane row
-  v += dpp_f<0x112, 0xf, true>(v);
-  v += dpp_f<0x114, 0xf, true>(v);
-  v += dpp_f<0x118, 0xf, true>(v);
-  v += dpp_f<0x142, 0xa, false>(v);  // row_bcast:15 into rows 1 and 3
-  v += dpp_f<0x143, 0xc, false>(v);  // row_bcast:31 into rows 2 and 3
-  return v;
-}
-// inclusive column prefix at column (2 lane + T) of the strip; p0 / p1 = prefix at this lane's columns
-template <int T>
-__device__ __forceinline__ float prefix_at(float p0, float p1, int lane) {
-  constexpr int SH = (T >= 0) ? T / 2 : -((1 - T) / 2), PAR = T - 2 * SH;
-  static_assert(PAR == 0 || PAR == 1, "floor division");
-  const int r = __builtin_amdgcn_ds_bpermute(((lane + SH) & 63) << 2, __builtin_bit_cast(int, PAR ? p1 : p0));
-  return __builtin_bit_cast(float, r);
-}
-
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
