@@ -845,6 +845,9 @@ chain1d_quad_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uin
             word[4 * e + i] = (uint32_t)(RSP_DBG_OUT == 1 ? cut[i] : RSP_DBG_OUT == 2 ? Pa[i] : RSP_DBG_OUT == 3 ? Me[i] : Pe[i]);
 #endif
           }
+          // one quad's loads at a time: hoisting all four quads' 24 LDS reads above the 64-bit threshold arithmetic
+          // took the FIXED16 kernel to 142 VGPRs (three workgroups per CU at 4096 points instead of four)
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     };
