@@ -67,3 +67,66 @@ def test_f32_random_configuration(gpu, seed):
     thr, peak, margin, mag = O.chain_f32(x, oracle_fcfg(params, rt), want_mag=True)
     short = rt.CFARMode == "CASH" or rt.refWindowSize <= 8     # short windows: prefix cancellation (see test_cash_mode)
     compare_f32(words, thr, peak, margin, mag, rtol=5e-5 if short else 2e-5, atol=2.0 ** -9 if rt.magMode == 1 else 0.0)
+
+
+# ------------------------------------------------------------------ 2-D chain
+
+def random_rd_case(rng):
+    nr = int(rng.choice([256, 512, 1024, 2048, 8192]))
+    nd = int(rng.choice([256, 512] if nr >= 2048 else [256, 512, 1024]))
+    rr = int(rng.choice([2, 4, 8, 16]))
+    gr = int(rng.integers(1, min(rr, 4)))          # refWindowSize > guardWindowSize > 0 (RspChainVanillaTester.scala:51-52)
+    rd, gd = int(rng.integers(1, 12)), int(rng.integers(0, 4))
+    if rng.random() < 0.3:
+        rr, gr, rd, gd = 8, 2, 8, 2                  # the compile-time windows of the strip walker
+    mode = str(rng.choice(["Cell Averaging", "Greatest Of", "Smallest Of"]))
+    edge = str(rng.choice(["zero", "wrap"]))
+    win = [None, "hann", "hamming", "blackman"]
+    return dict(nr=nr, nd=nd, rr=rr, gr=gr, rd=rd, gd=gd, mode=mode, edge=edge, n_ch=int(rng.integers(1, 4)),
+                window=win[int(rng.integers(0, 4))] if rng.random() < 0.4 else None,
+                windowDoppler=win[int(rng.integers(0, 4))] if rng.random() < 0.4 else None)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_rd2d_fixed_random_configuration(gpu, seed):
+    """2-D chain, FIXED16: bit-exact against orc_rd_fixed for random sizes, windows, modes, trims, magnitude modes."""
+    import test_gpu_rd2d as T
+    from helpers import WINDOWS
+    rng = np.random.default_rng(7100 + seed)
+    c = random_rd_case(rng)
+    mag = int(rng.choice([0, 1, 2, 2]))
+    params = T.rd_params_fx(c["nr"], c["nd"], ref=c["rd"], guard=c["gd"], edge=c["edge"], window=c["window"],
+                            windowDoppler=c["windowDoppler"], trim=str(rng.choice(["RoundDown", "RoundHalfUp", "Convergent"])),
+                            bp=int(rng.choice([8, 12])))
+    rt = R.RunTimeRspChainParams(fftSize=c["nr"], CFARMode=c["mode"], refWindowSize=c["rr"], guardWindowSize=c["gr"],
+                                 divSum=int(rng.integers(4, 10)), thresholdScaler=float(rng.choice([1.5, 3.0, 6.25])),
+                                 magMode=mag, logOrLinearMode=0 if (mag == 1 and rng.random() < 0.7) else 1)
+    beats, _ = T.targets_fx(c["n_ch"], c["nd"], c["nr"], seed=seed, noise=int(rng.choice([50, 800])), amp=int(rng.choice([3000, 20000])))
+    with R.FftMagCfarChainVanilla(params) as dut:
+        dut.configure(rt)
+        got = dut.stream(beats)
+    ref = T.fx_oracle(params, rt, beats, c["nd"], c["rd"], c["gd"], window_d=c["windowDoppler"])
+    assert np.array_equal(got, ref), c
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_rd2d_f32_random_configuration(gpu, seed):
+    import test_gpu_rd2d as T
+    from helpers import WINDOWS
+    rng = np.random.default_rng(7300 + seed)
+    c = random_rd_case(rng)
+    params = T.rd_params(c["nr"], c["nd"], ref=c["rd"], guard=c["gd"], edge=c["edge"], window=c["window"],
+                         windowDoppler=c["windowDoppler"])
+    rt = R.RunTimeRspChainParams(fftSize=c["nr"], CFARMode=c["mode"], refWindowSize=c["rr"], guardWindowSize=c["gr"], divSum=4,
+                                 thresholdScaler=4.0)
+    x, where = T.targets(c["n_ch"], c["nd"], c["nr"], seed=seed)
+    with R.FftMagCfarChainVanilla(params) as dut:
+        dut.configure(rt)
+        words = dut.stream(x)
+    cfg = O.OrcRdCfg(log2nr=R.log2Up(c["nr"]), log2nd=R.log2Up(c["nd"]), mag_mode=O.MAG_JPL, scaler=4.0, ref_r=c["rr"], ref_d=c["rd"],
+                     guard_r=c["gr"], guard_d=c["gd"], edge=1 if c["edge"] == "wrap" else 0, window_r=WINDOWS[c["window"]],
+                     window_d=WINDOWS[c["windowDoppler"]],
+                     cfar_mode={"Cell Averaging": O.CFAR_CA, "Greatest Of": O.CFAR_GO, "Smallest Of": O.CFAR_SO}[c["mode"]])
+    thr, peak, margin, mag = O.rd_f32(x, cfg, n_threads=4, want_mag=True)
+    n_ch = c["n_ch"]
+    compare_f32(words.reshape(n_ch, -1), thr.reshape(n_ch, -1), peak.reshape(n_ch, -1), margin.reshape(n_ch, -1), mag.reshape(n_ch, -1))
