@@ -550,13 +550,21 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
 // multiples of 4 the lagging positions k - G - R, k - G are quad-aligned; the leading ones
 // k + G + 1, k + G + R + 1 are off by one, so that side uses P[x + 1] = P[x] + m[x] at the aligned
 // x = k + G, k + G + R (two more quad reads of the magnitudes, no second prefix array).
-constexpr int kQHalo = 144;  // magnitude cells kept right of the frame: >= R + G + 4, a multiple of 16
+// Halo cells of the quad tail's images, in two sizes: windows with R + G + 4 <= 48 (every reference configuration:
+// R = 32, G = 4) take the SMALL one.  The halos are a fixed cost per frame, so they set the occupancy of SMALL
+// frames: with 144 / 256-cell halos a 1024-point frame takes 11.4 KiB (three 4-frame workgroups per CU), with
+// 48 / 64 cells 9.5 KiB (four) -- 53 -> 45.5 us per 16.7 M cells at 1024 points, 82 -> 43 us at 256 points.
+template <bool SMALL> struct QuadHalo {
+  static constexpr int MAG = SMALL ? 48 : 144;  // magnitude cells kept right of the frame: >= R + G + 4, a multiple of 16
+  static constexpr int PB = SMALL ? 64 : 256;   // prefix cells kept on either side of the frame: >= R + G + 4, a multiple of 16
+};
+constexpr int kQHalo = QuadHalo<false>::MAG;     // the largest window the quad tail serves: R + G + 4 <= 144
 
-template <int M>
+template <int M, bool SMALL>
 struct QuadLds {
-  static constexpr int N = 1 << M;
-  static constexpr int MAG_SLOTS = 16 + N + kQHalo;  // cell x in [-16, N + kQHalo) at x + 16
-  static constexpr int PB_SLOTS = N + 2 * kHalo;     // cell x in [-256, N + 256) at x + 256
+  static constexpr int N = 1 << M, QH = QuadHalo<SMALL>::MAG, PBH = QuadHalo<SMALL>::PB;
+  static constexpr int MAG_SLOTS = 16 + N + QH;      // cell x in [-16, N + QH) at x + 16
+  static constexpr int PB_SLOTS = N + 2 * PBH;       // cell x in [-PBH, N + PBH) at x + PBH
   static constexpr int BS_SLOTS = N / 256 + 3;       // blocks -1 .. N/256, + one slot that holds 0
   static constexpr int MAG_OFF = 0;
   static constexpr int PB_OFF = MAG_OFF + 4 * MAG_SLOTS;
@@ -615,7 +623,7 @@ __device__ __forceinline__ V seg_scan(V v) {
   return v;
 }
 
-template <int M, bool FIXED, int FX>
+template <int M, bool FIXED, int FX, bool SMALL>
 __global__ void __launch_bounds__(wg_size(M))
 chain1d_quad_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t n_frames,
                     ChainRegs rg, const void* __restrict__ tw, const int16_t* __restrict__ log_lut,
@@ -623,7 +631,8 @@ chain1d_quad_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uin
   constexpr int N = 1 << M, T = threads_per_frame(M), FPW = frames_per_wg(M);
   constexpr int WD = T < 64 ? T : 64;  // lanes of a wave that belong to one frame
   constexpr int SPB = 64 / WD;         // lane segments (values of e) per 256-cell block
-  using L = QuadLds<M>;
+  using L = QuadLds<M, SMALL>;
+  constexpr int QH = L::QH, PBH = L::PBH;
   using V = typename std::conditional<FIXED, int, float>::type;
   using V4 = typename Vec4<V>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -641,8 +650,8 @@ chain1d_quad_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uin
                          reinterpret_cast<uint32_t*>(smem + (size_t)L::BYTES * FPW), mg STAMP_ARG);
   STAMP(7);
 
-  V* mag = reinterpret_cast<V*>(fbase + L::MAG_OFF) + 16;   // mag[x], x in [-16, N + kQHalo)
-  V* pb = reinterpret_cast<V*>(fbase + L::PB_OFF) + kHalo;  // pb[x], x in [-256, N + 256)
+  V* mag = reinterpret_cast<V*>(fbase + L::MAG_OFF) + 16;   // mag[x], x in [-16, N + QH)
+  V* pb = reinterpret_cast<V*>(fbase + L::PB_OFF) + PBH;    // pb[x], x in [-PBH, N + PBH)
   V* bs = reinterpret_cast<V*>(fbase + L::BS_OFF) + 1;      // bs[-1] .. bs[N/256], bs[N/256 + 1] = 0
   uint32_t* det_cnt = reinterpret_cast<uint32_t*>(fbase + L::DET_OFF);
   uint2* det_stage = reinterpret_cast<uint2*>(fbase + L::DET_OFF + 8);
@@ -706,13 +715,13 @@ chain1d_quad_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uin
       }
       const V4 pq = V4{V(0), p1[e], p2[e], p3[e]} + exc;
       *reinterpret_cast<V4*>(pb + 4 * q) = pq;
-      // halos: zeros, or the wrapped image of the first / last block (prefixes), of the first kQHalo
+      // halos: zeros, or the wrapped image of the first / last block (prefixes), of the first QH
       // cells (magnitudes right of the frame) and of the last cell (left neighbour of cell 0)
-      if (q < 64) {
+      if (q < PBH / 4) {
         *reinterpret_cast<V4*>(pb + 4 * q + N) = wrap ? pq : zero4;
-        if (q < kQHalo / 4) *reinterpret_cast<V4*>(mag + 4 * q + N) = wrap ? mq[e] : zero4;
+        if (q < QH / 4) *reinterpret_cast<V4*>(mag + 4 * q + N) = wrap ? mq[e] : zero4;
       }
-      if (q >= N / 4 - 64) *reinterpret_cast<V4*>(pb + 4 * q - N) = wrap ? pq : zero4;
+      if (q >= N / 4 - PBH / 4) *reinterpret_cast<V4*>(pb + 4 * q - N) = wrap ? pq : zero4;
       if (q == N / 4 - 1) mag[-1] = wrap ? mq[e][3] : V(0);
     }
     // block totals: the lane that holds a block's last quad (for T >= 64 the same lane for every e)
@@ -1269,16 +1278,20 @@ template <int M>
 static hipError_t launch_quad(const Chain1dLaunch& a) {
   const uint32_t fpw = frames_per_wg(M);
   const uint32_t grid = (a.n_frames + fpw - 1) / fpw;
-  const size_t lds = QuadLds<M>::BYTES * fpw + (kPartFixed ? QuadLds<M>::ROM_BYTES : 0);
   return with_fx(a, [&](auto fx) -> hipError_t {
     constexpr int FX = decltype(fx)::value;
-    static LdsGrant granted;
-    auto k = chain1d_quad_kernel<M, kPartFixed, FX>;
-    hipError_t e = grant_lds(k, lds, a.device, granted);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(wg_size(M)), lds, a.stream, a.in, a.out, a.n_frames,
-                       a.regs, a.twiddles, a.log_lut, a.frame_count, a.frame_det);
-    return hipGetLastError();
+    auto go = [&](auto small_c, LdsGrant& granted) -> hipError_t {
+      constexpr bool SMALL = decltype(small_c)::value;
+      const size_t lds = QuadLds<M, SMALL>::BYTES * fpw + (kPartFixed ? QuadLds<M, SMALL>::ROM_BYTES : 0);
+      auto k = chain1d_quad_kernel<M, kPartFixed, FX, SMALL>;
+      hipError_t e = grant_lds(k, lds, a.device, granted);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(k, dim3(grid), dim3(wg_size(M)), lds, a.stream, a.in, a.out, a.n_frames,
+                         a.regs, a.twiddles, a.log_lut, a.frame_count, a.frame_det);
+      return hipGetLastError();
+    };
+    static LdsGrant g2[2];
+    return a.regs.R + a.regs.G + 4 <= QuadHalo<true>::MAG ? go(std::true_type{}, g2[0]) : go(std::false_type{}, g2[1]);
   });
 }
 
