@@ -1,7 +1,8 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): the round's bench line, rocprofv3 kernel stats of the SAME command, separate
 # --pmc passes (HBM traffic, SQ / LDS counters) of the headline kernel and of the 2-D chain, the 1-rank RCCL
-# rehearsal of the multi-GPU (cfg5) line and the PCIe-inclusive rate.  Output under gpurun_out/<round>/;
+# rehearsal of the multi-GPU (cfg5) line and the PCIe-inclusive rate.  Output under gpurun_out/<round>/ (gpurun MERGES
+# it into the local copy: delete the local gpurun_out/<round>/collect first, or old runs' files are summarised too);
 # tools/summarise_profiles.py turns it into profiles/ (tracked).
 RND=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
