@@ -40,8 +40,13 @@ __device__ __forceinline__ float mag2d(f32x2 z, int mode) {
 // 128-B lines (+8 us) and the CFAR walker reads 64-B segments of sequential streams (+5 us).  At 4096 x 512 the tiling
 // costs 4 us more than it saves.  RSP_RD_TILE=0 / 16 force one layout for A/B runs.
 constexpr uint32_t kTileCols = 16;
+#ifndef RSP_RD_MAGTILE
+#define RSP_RD_MAGTILE 16
+#endif
+constexpr uint32_t kMagTileCols = RSP_RD_MAGTILE;  // tile width of the magnitude map
+template <uint32_t W = kTileCols>
 __host__ __device__ __forceinline__ size_t map_index(uint32_t d, uint32_t r, uint32_t nd, uint32_t nr, uint32_t tile) {
-  return tile ? ((size_t)(r / kTileCols) * nd + d) * kTileCols + (r % kTileCols) : (size_t)d * nr + r;
+  return tile ? ((size_t)(r / W) * nd + d) * W + (r % W) : (size_t)d * nr + r;
 }
 static inline uint32_t rd_tile(int log2nr) {
 #ifdef RSP_RD_TILE
@@ -65,7 +70,11 @@ range_fft_kernel(const f32x2* __restrict__ in, f32x2* __restrict__ out, uint32_t
   const bool live = row < n_rows;
   if (zero_count && blockIdx.x == 0 && tid == 0) zero_count[0] = zero_count[1] = 0u;  // the detection list's {found, stored}
   f32x2* buf = reinterpret_cast<f32x2*>(smem) + (size_t)fl * fft_image_slots(M);
+#ifdef RSP_ABL_RANGE_L2  // ablation builds: every workgroup reads rows 0..63 (L2-resident source)
+  const f32x2* src = in + (size_t)(live ? (row & 63) : 0) * N + first_sample<M>(tau);
+#else
   const f32x2* src = in + (size_t)(live ? row : 0) * N + first_sample<M>(tau);
+#endif
   f32x2 x[16];
   if (win) {  // fast-time window (build extension)
     const float* wsrc = win + first_sample<M>(tau);
@@ -78,6 +87,9 @@ range_fft_kernel(const f32x2* __restrict__ in, f32x2* __restrict__ out, uint32_t
   constexpr int NP = plan_np(M), WL = plan_w(M, NP - 1);
   const float scale = 1.0f / (float)N;
   if (!live) return;
+#ifdef RSP_ABL_RANGE_NOSTORE
+  if (log2nd != 77u) return;
+#endif
   if constexpr (!TILED) {
     f32x2* dst = out + (size_t)row * N + tau;
 #pragma unroll
@@ -134,8 +146,9 @@ doppler_mag_kernel(const f32x2* __restrict__ in, float* __restrict__ mag, uint32
   const uint32_t ch = wg / tiles_per_ch, r0 = (wg % tiles_per_ch) * C;
   f32x2* buf = reinterpret_cast<f32x2*>(smem + (size_t)fl * kColBytes(MD));
   // element index of (ch, d = 0, r) and the distance between Doppler rows, in each of the two maps
-  const size_t col = (size_t)ch * ND * nr + map_index(0, r0 + fl, ND, nr, tile), mcol = col;
-  const uint32_t pitch = tile ? kTileCols : nr, mpitch = pitch;
+  const size_t col = (size_t)ch * ND * nr + map_index(0, r0 + fl, ND, nr, tile);
+  const size_t mcol = (size_t)ch * ND * nr + map_index<kMagTileCols>(0, r0 + fl, ND, nr, tile);
+  const uint32_t pitch = tile ? kTileCols : nr, mpitch = tile ? kMagTileCols : nr;
   const f32x2* src = in + col + (size_t)first_sample<MD>(tau) * pitch;
   f32x2 x[16];
   if (win) {  // slow-time window
@@ -252,13 +265,14 @@ doppler_fx_kernel(const uint32_t* __restrict__ in, int32_t* __restrict__ mag, ui
   __syncthreads();
   fft_fx_frame<MD>(xr, xi, tau, fbase, rom, rg);
   constexpr int NP = plan_np(MD), WL = plan_w(MD, NP - 1);
-  int32_t* dst = mag + col;
+  int32_t* dst = mag + (size_t)ch * ND * nr + map_index<kMagTileCols>(0, r0 + fl, ND, nr, tile);
+  const uint32_t mpitch = tile ? kMagTileCols : nr;
 #pragma unroll
   for (int g = 0; g < (16 >> WL); ++g) {
 #pragma unroll
     for (int p = 0; p < (1 << WL); ++p) {
       const int e = g * (1 << WL) + p;
-      dst[(size_t)bin_of<MD>(tau, g, p) * pitch] = mag_fx(xr[e], xi[e], rg, log_lut);
+      dst[(size_t)bin_of<MD>(tau, g, p) * mpitch] = mag_fx(xr[e], xi[e], rg, log_lut);
     }
   }
 }
@@ -337,7 +351,7 @@ cfar2d_kernel(const T* __restrict__ mag, uint32_t* __restrict__ out, uint32_t nd
       for (int u = 0; u < 16; ++u) {
         const int dd = base + 2 * u;
         const int d = (d0 - hd + dd + (int)nd) & ((int)nd - 1);  // Doppler cyclic (nd is a power of two)
-        v[u] = (inside && dd < RH) ? map[map_index((uint32_t)d, (uint32_t)r, nd, nr, tile)] : T(0);
+        v[u] = (inside && dd < RH) ? map[map_index<kMagTileCols>((uint32_t)d, (uint32_t)r, nd, nr, tile)] : T(0);
       }
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
@@ -570,8 +584,8 @@ cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, ui
       __builtin_amdgcn_make_buffer_rsrc(out + (size_t)ch * nd * nr, 0, (int)map_bytes, (int)kRsrc3);
   const bool readable = edge || (col >= 0 && col < (int)nr);
   const bool owner = lane >= LB && lane <= LE && col < (int)nr;
-  const uint32_t voff_in = readable ? (uint32_t)map_index(0, (uint32_t)(col & ((int)nr - 1)), nd, nr, tile) * 4u : kOob;
-  const uint32_t row_bytes = (tile ? kTileCols : nr) * 4u;  // address step between Doppler rows of the magnitude map
+  const uint32_t voff_in = readable ? (uint32_t)map_index<kMagTileCols>(0, (uint32_t)(col & ((int)nr - 1)), nd, nr, tile) * 4u : kOob;
+  const uint32_t row_bytes = (tile ? kMagTileCols : nr) * 4u;  // address step between Doppler rows of the magnitude map
 #ifdef RSP_ABL_WALK_NOSTORE  // ablation builds (tools/ablate_rd.sh): never defined in the product
   const uint32_t voff_out = kOob;
 #else
