@@ -176,6 +176,70 @@ doppler_mag_kernel(const f32x2* __restrict__ in, float* __restrict__ mag, uint32
   }
 }
 
+// 1024 Doppler bins: only 8 column images fit the LDS of a workgroup, and 8 columns are half a 128-B line of either
+// map.  This form handles 16 columns with the same 8 images: every thread loads column PAIRS (16-byte loads: whole lines
+// per 8 lanes), transforms the even columns, keeps their magnitudes, transforms the odd columns through the same
+// images, and stores magnitude pairs (8 B per lane, whole lines per 16 lanes) -- half as many L2 requests per byte.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef RSP_DOPPLER_PAIR
+#define RSP_DOPPLER_PAIR 1
+#endif
+#ifndef RSP_DOPPLER_PAIR_FROM
+#define RSP_DOPPLER_PAIR_FROM 10   // Doppler sizes (log2) from which the paired form is used
+#endif
+template <int MD>
+__global__ void __launch_bounds__(threads_per_frame(MD) * kColsPerWg(MD))
+doppler_mag_pair_kernel(const f32x2* __restrict__ in, float* __restrict__ mag, uint32_t n_ch, uint32_t nr, uint32_t tile,
+                        int mag_mode, const f32x2* __restrict__ tw, const float* __restrict__ win) {
+  constexpr int ND = 1 << MD, C2 = kColsPerWg(MD);  // column PAIRS per workgroup = LDS images
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, fl = tid % C2, tau = tid / C2;
+  const uint32_t groups_per_ch = nr / (2 * C2);
+  const uint32_t ch = blockIdx.x / groups_per_ch, r0 = (blockIdx.x % groups_per_ch) * (2 * C2) + 2 * fl;
+  f32x2* buf = reinterpret_cast<f32x2*>(smem + (size_t)fl * kColBytes(MD));
+  const size_t col = (size_t)ch * ND * nr + map_index(0, r0, ND, nr, tile);
+  const size_t mcol = (size_t)ch * ND * nr + map_index<kMagTileCols>(0, r0, ND, nr, tile);
+  const uint32_t pitch = tile ? kTileCols : nr, mpitch = tile ? kMagTileCols : nr;
+  const int s0 = first_sample<MD>(tau);
+  f32x4 raw[16];
+  {
+    const f32x2* src = in + col + (size_t)s0 * pitch;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) raw[e] = *reinterpret_cast<const f32x4*>(src + (size_t)sample_offset<MD>(e) * pitch);
+    if (win) {  // slow-time window: one coefficient per row, the same for both columns
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float wv = win[s0 + sample_offset<MD>(e)];
+        raw[e] = raw[e] * f32x4{wv, wv, wv, wv};
+      }
+    }
+  }
+  constexpr int NP = plan_np(MD), WL = plan_w(MD, NP - 1);
+  const float scale = 1.0f / (float)ND;
+  f32x2 x[16];
+  float m0[16];
+  {
+    int e = 0;
+    fft_f32_frame<MD>([&](int) { const f32x4 r = raw[e++]; return f32x2{r.x, r.y}; }, tau, buf, tw, x);
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) m0[e] = mag2d(x[e] * scale, mag_mode);
+  __syncthreads();  // the images are rewritten by the second transform's first exchange
+  {
+    int e = 0;
+    fft_f32_frame<MD>([&](int) { const f32x4 r = raw[e++]; return f32x2{r.z, r.w}; }, tau, buf, tw, x);
+  }
+  float* dst = mag + mcol;
+#pragma unroll
+  for (int g = 0; g < (16 >> WL); ++g) {
+#pragma unroll
+    for (int p = 0; p < (1 << WL); ++p) {
+      const int e = g * (1 << WL) + p;
+      *reinterpret_cast<f32x2*>(dst + (size_t)bin_of<MD>(tau, g, p) * mpitch) = f32x2{m0[e], mag2d(x[e] * scale, mag_mode)};
+    }
+  }
+}
+
 // ---------------------------------------------------------------- FIXED16 passes (build extension, oracle: orc_rd_fixed)
 // The same two passes on the 16-bit FixedPoint data path: beats {re[31:16], im[15:0]} in, the range spectrum kept as
 // beats (4 B/cell), both FFTs with the stage-exact arithmetic of fft_fx_frame (Q2.14 ROM in LDS), Q1.15 windows,
@@ -734,15 +798,26 @@ static hipError_t launch_range_m(const f32x2* in, f32x2* out, uint32_t n_rows, i
 template <int MD>
 static hipError_t launch_doppler_m(const f32x2* in, float* mag, uint32_t n_ch, uint32_t nr, uint32_t tile, int mode,
                                    const f32x2* tw, const float* win, hipStream_t s, int device) {
-  constexpr int C = kColsPerWg(MD);
-  const size_t lds = (size_t)kColBytes(MD) * C;
-  auto k = doppler_mag_kernel<MD>;
-  static LdsGrant granted;
-  hipError_t e = grant_lds(k, lds, device, granted);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k, dim3(n_ch * (nr / C)), dim3(threads_per_frame(MD) * C), lds, s, in, mag, n_ch,
-                     nr, tile, mode, tw, win);
-  return hipGetLastError();
+  if constexpr (MD >= (RSP_DOPPLER_PAIR_FROM) && (RSP_DOPPLER_PAIR)) {  // two columns per LDS image (see doppler_mag_pair_kernel)
+    constexpr int C2 = kColsPerWg(MD);
+    const size_t lds = (size_t)kColBytes(MD) * C2;
+    auto k = doppler_mag_pair_kernel<MD>;
+    static LdsGrant granted;
+    hipError_t e = grant_lds(k, lds, device, granted);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(n_ch * (nr / (2 * C2))), dim3(threads_per_frame(MD) * C2), lds, s, in, mag, n_ch, nr, tile, mode, tw, win);
+    return hipGetLastError();
+  } else {
+    constexpr int C = kColsPerWg(MD);
+    const size_t lds = (size_t)kColBytes(MD) * C;
+    auto k = doppler_mag_kernel<MD>;
+    static LdsGrant granted;
+    hipError_t e = grant_lds(k, lds, device, granted);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(n_ch * (nr / C)), dim3(threads_per_frame(MD) * C), lds, s, in, mag, n_ch,
+                       nr, tile, mode, tw, win);
+    return hipGetLastError();
+  }
 }
 
 // one chunk of channels through the three kernels; scratch buffers are the chunk's own
