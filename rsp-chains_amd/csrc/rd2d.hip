@@ -546,69 +546,76 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // row before it finishes the previous row (walk_issue holds no arithmetic on a ds_bpermute result): a step then
 // never waits for the crossbar round trip it has just started.  (A DPP prefix scan + 8 ds_bpermute taps per step
 // measured 33.5 us at 8 x 4096 x 512; these sums 32.2 us; issued one step ahead: see DESIGN 3.2.)
-struct WalkBox { f32x2 box, lag; };
-__device__ __forceinline__ float lane_up1(float v) { return dpp_f<0x138, 0xf, true>(v); }  // wave_shr:1: lane l - 1
-__device__ __forceinline__ float lane_dn1(float v) { return dpp_f<0x130, 0xf, true>(v); }  // wave_shl:1: lane l + 1
-template <int K>
-__device__ __forceinline__ float lane_at(float v, int lane) {  // value of lane l + K
+// S = float (fp32 maps) or int32_t (FIXED16 magnitudes: exact integer sums)
+template <typename S> struct Pair { typedef S type __attribute__((ext_vector_type(2))); };
+template <typename S> struct WalkBox { typename Pair<S>::type box, lag; };
+template <int CTRL, typename S>
+__device__ __forceinline__ S dpp_s(S v) {
+  return __builtin_bit_cast(S, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <typename S> __device__ __forceinline__ S lane_up1(S v) { return dpp_s<0x138, S>(v); }  // wave_shr:1: lane l - 1
+template <typename S> __device__ __forceinline__ S lane_dn1(S v) { return dpp_s<0x130, S>(v); }  // wave_shl:1: lane l + 1
+template <int K, typename S>
+__device__ __forceinline__ S lane_at(S v, int lane) {  // value of lane l + K
   if constexpr (K == 0) return v;
   else if constexpr (K == -1) return lane_up1(v);
   else if constexpr (K == 1) return lane_dn1(v);
-  else return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane + K) & 63) << 2, __builtin_bit_cast(int, v)));
+  else return __builtin_bit_cast(S, __builtin_amdgcn_ds_bpermute(((lane + K) & 63) << 2, __builtin_bit_cast(int, v)));
 }
 constexpr int lane_runs(int n) { return n <= 0 ? 0 : n / 4 + ((n % 4) >= 2) + (n % 2); }
 // the runs a_k[m] = s[m - 2^k + 1 .. m] (k <= 2) that tile lanes l + FIRST .. l + FIRST + N - 1, longest first, into out[I..]
-template <int FIRST, int N, int I = 0, int NT>
-__device__ __forceinline__ void lane_run_taps(float s, float a1, float a2, int lane, float (&out)[NT]) {
+template <int FIRST, int N, int I = 0, typename S, int NT>
+__device__ __forceinline__ void lane_run_taps(S s, S a1, S a2, int lane, S (&out)[NT]) {
   if constexpr (N > 0) {
     constexpr int k = N >= 4 ? 2 : N >= 2 ? 1 : 0, last = FIRST + N - 1;
     out[I] = lane_at<last>(k == 2 ? a2 : k == 1 ? a1 : s, lane);
     lane_run_taps<FIRST, N - (1 << k), I + 1>(s, a1, a2, lane, out);
   }
 }
-template <int H, bool LAG>
+template <int H, bool LAG, typename S>
 struct WalkTaps {
   static constexpr int h = H / 2, NC = h == 1 ? 1 : lane_runs(2 * h), NM = (h == 1 || !LAG) ? 1 : lane_runs(h - 1);
-  float core[NC], mid[NM], ym, sm, yp, x;
+  S core[NC], mid[NM], ym, sm, yp, x;
 };
-template <int H, bool LAG>
-__device__ __forceinline__ WalkTaps<H, LAG> walk_issue(f32x2 v, int lane) {
+template <int H, bool LAG, typename S>
+__device__ __forceinline__ WalkTaps<H, LAG, S> walk_issue(typename Pair<S>::type v, int lane) {
   static_assert(H % 2 == 0 && H >= 2 && H <= 30, "even half-width");
   constexpr int h = H / 2;
-  const float s = v.x + v.y;
-  WalkTaps<H, LAG> t;
+  const S s = v.x + v.y;
+  WalkTaps<H, LAG, S> t;
   t.x = v.x;
   if constexpr (h == 1) {  // one-lane shifts only: no crossbar
-    t.core[0] = s; t.mid[0] = 0.f;
-    t.sm = lane_up1(s); t.ym = lane_up1(v.y); t.yp = lane_dn1(v.x); t.x = lane_dn1(s);
+    t.core[0] = s; t.mid[0] = S(0);
+    t.sm = lane_up1(s); t.ym = lane_up1((S)v.y); t.yp = lane_dn1((S)v.x); t.x = lane_dn1(s);
   } else {
     // runs of 2 and 4 lanes ending at this lane, built with wave shifts only: every ds_bpermute depends on VALU results alone
-    const float a1 = s + lane_up1(s);
-    const float a2 = a1 + lane_up1(lane_up1(a1));
+    const S a1 = s + lane_up1(s);
+    const S a2 = a1 + lane_up1(lane_up1(a1));
     lane_run_taps<-h + 1, 2 * h>(s, a1, a2, lane, t.core);  // lanes l - h + 1 .. l + h (columns 2l - 2h + 2 .. 2l + 2h + 1)
     if constexpr (LAG) lane_run_taps<-h + 1, h - 1>(s, a1, a2, lane, t.mid);  // lanes l - h + 1 .. l - 1
-    else t.mid[0] = 0.f;
-    t.ym = lane_at<-h>(v.y, lane); t.sm = lane_at<-h>(s, lane); t.yp = lane_at<h>(v.y, lane);
+    else t.mid[0] = S(0);
+    t.ym = lane_at<-h>((S)v.y, lane); t.sm = lane_at<-h>(s, lane); t.yp = lane_at<h>((S)v.y, lane);
   }
   return t;
 }
-template <int H, bool LAG>
-__device__ __forceinline__ WalkBox walk_finish(const WalkTaps<H, LAG>& t, f32x2 v) {
+template <int H, bool LAG, typename S>
+__device__ __forceinline__ WalkBox<S> walk_finish(const WalkTaps<H, LAG, S>& t, typename Pair<S>::type v) {
+  typedef typename Pair<S>::type S2;
   constexpr int h = H / 2;
-  WalkBox r;
+  WalkBox<S> r;
   if constexpr (h == 1) {
     // box(2l) = s[l-1] + s[l] + x[l+1], box(2l+1) = y[l-1] + s[l] + s[l+1]; lag(2l) = s[l-1], lag(2l+1) = y[l-1] + x[l]
-    r.box = f32x2{(t.sm + t.core[0]) + t.yp, (t.ym + t.core[0]) + t.x};
-    r.lag = f32x2{t.sm, t.ym + v.x};
+    r.box = S2{(t.sm + t.core[0]) + t.yp, (t.ym + t.core[0]) + t.x};
+    r.lag = S2{t.sm, t.ym + v.x};
   } else {
-    float core = t.core[0], mid = t.mid[0];
+    S core = t.core[0], mid = t.mid[0];
 #pragma unroll
-    for (int k = 1; k < WalkTaps<H, LAG>::NC; ++k) core += t.core[k];
+    for (int k = 1; k < WalkTaps<H, LAG, S>::NC; ++k) core += t.core[k];
 #pragma unroll
-    for (int k = 1; k < WalkTaps<H, LAG>::NM; ++k) mid += t.mid[k];
-    r.box = f32x2{(core + t.sm) - t.yp, core + t.ym};
+    for (int k = 1; k < WalkTaps<H, LAG, S>::NM; ++k) mid += t.mid[k];
+    r.box = S2{(core + t.sm) - t.yp, core + t.ym};
     // lagging columns: lanes l - h + 1 .. l - 1 whole, plus lane l - h (whole / upper column) and column 2l for c = 2l + 1
-    r.lag = f32x2{mid + t.sm, (mid + t.ym) + v.x};
+    r.lag = S2{mid + t.sm, (mid + t.ym) + v.x};
   }
   return r;
 }
@@ -621,12 +628,14 @@ constexpr int walk_lb(int hr) { return (hr + 2) / 2; }
 constexpr int walk_le(int hr) { return (126 - hr) / 2; }
 constexpr int walk_outw(int hr) { return 2 * (walk_le(hr) - walk_lb(hr) + 1); }
 
-template <int RR, int GR, int RD, int GD, int SEG, int MODE>
+template <int RR, int GR, int RD, int GD, int SEG, int MODE, typename S = float>
 __global__ void __launch_bounds__(256)
-cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, uint32_t nd, uint32_t nr,
+cfar2d_walk_kernel(const S* __restrict__ mag, uint32_t* __restrict__ out, uint32_t nd, uint32_t nr,
                    uint32_t strips, int edge, float kA, float kB,
                    rsp_detection* __restrict__ det_list, uint32_t det_cap, uint32_t* __restrict__ det_count, uint32_t ch_base,
-                   uint32_t tile) {
+                   uint32_t tile, ChainRegs rg, int log2nr) {
+  typedef typename Pair<S>::type S2;
+  constexpr bool FX = !std::is_same<S, float>::value;  // FIXED16 magnitudes: integer sums, thresholds through CfarMath<int>
   constexpr int HR = RR + GR, HD = RD + GD, SPAN = 2 * HD + 2, RING = kWalkRing;
   constexpr int LB = walk_lb(HR), LE = walk_le(HR), OUTW = walk_outw(HR);
   static_assert(SPAN < RING && SEG % RING == 0, "ring holds the taps plus at least one row in flight");
@@ -643,7 +652,7 @@ cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, ui
   constexpr uint32_t kOob = 0xfffffff0u, kRsrc3 = 0x00020000u;
   const uint32_t map_bytes = nd * nr * 4u;
   const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(mag) + (size_t)ch * nd * nr, 0, (int)map_bytes, (int)kRsrc3);
+      const_cast<S*>(mag) + (size_t)ch * nd * nr, 0, (int)map_bytes, (int)kRsrc3);
   const __amdgpu_buffer_rsrc_t rsrc_out =
       __builtin_amdgcn_make_buffer_rsrc(out + (size_t)ch * nd * nr, 0, (int)map_bytes, (int)kRsrc3);
   const bool readable = edge || (col >= 0 && col < (int)nr);
@@ -661,13 +670,13 @@ cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, ui
   // HD - p): a segment's halo rows are then read at the same time as its neighbour in the workgroup reads them as
   // its own (both at the start or both at the end of their walks), i.e. once from HBM instead of twice
   const bool up = RSP_WALK_ALTERNATE && (w & 1);
-  auto load_row = [&](int p) -> f32x2 {
+  auto load_row = [&](int p) -> S2 {
 #ifdef RSP_ABL_WALK_ROW0
     const uint32_t d = (uint32_t)(p & 31);
 #else
     const uint32_t d = (uint32_t)((up ? d0 + SEG - 1 + HD - p : d0 - HD + p) & ((int)nd - 1));
 #endif
-    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_in, voff_in, d * row_bytes, 0));
+    return __builtin_bit_cast(S2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_in, voff_in, d * row_bytes, 0));
   };
   // fused detection list: peaks are staged in a wave-private LDS buffer during the walk (LDS atomics
   // only: a vector-memory atomic inside the walk, even in a never-taken branch, makes the wait-count
@@ -676,17 +685,17 @@ cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, ui
   __shared__ u32x4 stage[4][kWalkStage];
   const uint32_t det_mask = (det_list && owner) ? 1u : 0u;
   if (lane == 0) stage_cnt[w] = 0u;
-  f32x2 ring[RING];
+  S2 ring[RING];
 #pragma unroll
   for (int p = 0; p < RING - 1; ++p) ring[p] = load_row(p);
-  f32x2 vo = ring[0], vi = ring[HD - GD];
+  S2 vo = ring[0], vi = ring[HD - GD];
 #pragma unroll
   for (int p = 1; p <= 2 * HD; ++p) vo += ring[p];
 #pragma unroll
   for (int p = HD - GD + 1; p <= HD + GD; ++p) vi += ring[p];
   // GO / SO: the RD rows of the CUT's own column at smaller Doppler than the guard band belong to the lagging half:
   // the first RD rows of the window when walking down, the last RD when walking up
-  f32x2 vup = {0.f, 0.f};
+  S2 vup = {S(0), S(0)};
   if constexpr (MODE != 0) {
     if (up) {
 #pragma unroll
@@ -699,37 +708,53 @@ cfar2d_walk_kernel(const float* __restrict__ mag, uint32_t* __restrict__ out, ui
   const float kAh = 2.0f * kAc;
   constexpr bool LAG = MODE != 0;
   // software pipeline, one step deep: the cross-lane reads of row i + 1 are in flight while row i is finished
-  WalkTaps<HR, LAG> to = walk_issue<HR, LAG>(vo, lane);
-  WalkTaps<GR, LAG> ti = walk_issue<GR, LAG>(vi, lane);
-  f32x2 vo_cur = vo, vi_cur = vi, vup_cur = vup;
+  WalkTaps<HR, LAG, S> to = walk_issue<HR, LAG, S>(vo, lane);
+  WalkTaps<GR, LAG, S> ti = walk_issue<GR, LAG, S>(vi, lane);
+  S2 vo_cur = vo, vi_cur = vi, vup_cur = vup;
   for (int chunk = 0; chunk < SEG / RING; ++chunk) {
 #pragma unroll
     for (int u = 0; u < RING; ++u) {
       const int i = chunk * RING + u;
       if (i + RING - 1 < SEG + 2 * HD) ring[(u + RING - 1) % RING] = load_row(i + RING - 1);  // rows past the walk's last window are not read
-      const f32x2 cut = ring[(u + HD) % RING];
+      const S2 cut = ring[(u + HD) % RING];
       // column sums of row i + 1 and its cross-lane reads (the last step's are never used)
       vo += ring[(u + SPAN - 1) % RING] - ring[u];
       vi += ring[(u + HD + GD + 1) % RING] - ring[(u + HD - GD) % RING];
       if constexpr (LAG) vup += up ? ring[(u + SPAN - 1) % RING] - ring[(u + HD + GD + 1) % RING] : ring[(u + RD) % RING] - ring[u];
-      const WalkTaps<HR, LAG> to_next = walk_issue<HR, LAG>(vo, lane);
-      const WalkTaps<GR, LAG> ti_next = walk_issue<GR, LAG>(vi, lane);
+      const WalkTaps<HR, LAG, S> to_next = walk_issue<HR, LAG, S>(vo, lane);
+      const WalkTaps<GR, LAG, S> ti_next = walk_issue<GR, LAG, S>(vi, lane);
       __builtin_amdgcn_sched_barrier(0);
-      const WalkBox bo = walk_finish<HR, LAG>(to, vo_cur), bi = walk_finish<GR, LAG>(ti, vi_cur);
-      float t0, t1;
-      if constexpr (MODE == 0) {
-        t0 = __fmaf_rn(bo.box.x - bi.box.x, kAc, kB);
-        t1 = __fmaf_rn(bo.box.y - bi.box.y, kAc, kB);
-      } else {
-        // lagging half: columns c - H .. c - 1 of the box sums + the rows of column c above the guard; leading half =
-        // the rest of the training region
-        const f32x2 lag = (bo.lag - bi.lag) + vup_cur, lead = (bo.box - bi.box) - lag;
-        t0 = __fmaf_rn(MODE == 1 ? fmaxf(lag.x, lead.x) : fminf(lag.x, lead.x), kAh, kB);
-        t1 = __fmaf_rn(MODE == 1 ? fmaxf(lag.y, lead.y) : fminf(lag.y, lead.y), kAh, kB);
-      }
+      const WalkBox<S> bo = walk_finish<HR, LAG, S>(to, vo_cur), bi = walk_finish<GR, LAG, S>(ti, vi_cur);
       u32x2 wd;
-      wd.x = (__float_as_uint(t0) & ~1u) | (uint32_t)(cut.x > t0);
-      wd.y = (__float_as_uint(t1) & ~1u) | (uint32_t)(cut.y > t1);
+      if constexpr (FX) {
+        // orc_rd_fixed: CA: training sum >> div_sum; GO / SO: each half's sum >> (div_sum - 1), the greater / smaller
+        S2 stat;
+        if constexpr (MODE == 0) {
+          const S2 sum = bo.box - bi.box;
+          stat = S2{sum.x >> rg.div_sum, sum.y >> rg.div_sum};
+        } else {
+          const int sh = rg.div_sum > 0 ? rg.div_sum - 1 : 0;
+          const S2 lag = (bo.lag - bi.lag) + vup_cur, lead = (bo.box - bi.box) - lag;
+          const S2 lg = S2{lag.x >> sh, lag.y >> sh}, ld = S2{lead.x >> sh, lead.y >> sh};
+          stat = S2{MODE == 1 ? max(lg.x, ld.x) : min(lg.x, ld.x), MODE == 1 ? max(lg.y, ld.y) : min(lg.y, ld.y)};
+        }
+        wd.x = CfarMath<int>::finish(stat.x, cut.x, true, col, log2nr, rg);
+        wd.y = CfarMath<int>::finish(stat.y, cut.y, true, col + 1, log2nr, rg);
+      } else {
+        float t0, t1;
+        if constexpr (MODE == 0) {
+          t0 = __fmaf_rn(bo.box.x - bi.box.x, kAc, kB);
+          t1 = __fmaf_rn(bo.box.y - bi.box.y, kAc, kB);
+        } else {
+          // lagging half: columns c - H .. c - 1 of the box sums + the rows of column c above the guard; leading half =
+          // the rest of the training region
+          const S2 lag = (bo.lag - bi.lag) + vup_cur, lead = (bo.box - bi.box) - lag;
+          t0 = __fmaf_rn(MODE == 1 ? fmaxf(lag.x, lead.x) : fminf(lag.x, lead.x), kAh, kB);
+          t1 = __fmaf_rn(MODE == 1 ? fmaxf(lag.y, lead.y) : fminf(lag.y, lead.y), kAh, kB);
+        }
+        wd.x = (__float_as_uint(t0) & ~1u) | (uint32_t)(cut.x > t0);
+        wd.y = (__float_as_uint(t1) & ~1u) | (uint32_t)(cut.y > t1);
+      }
       const uint32_t d_out = (uint32_t)(up ? d0 + SEG - 1 - i : d0 + i);
       __builtin_amdgcn_raw_buffer_store_b64(wd, rsrc_out, voff_out, d_out * nr * 4u, 0);
       if ((wd.x | wd.y) & det_mask) {  // rare
@@ -870,7 +895,7 @@ static hipError_t launch_rd2d_chunk(const Rd2dLaunch& a, uint32_t ch0, uint32_t 
     const dim3 grid(n_ch * strips * (nd / SEG / 4));
 #define RSP_WALK(MODE)                                                                                              \
   hipLaunchKernelGGL((cfar2d_walk_kernel<8, 2, 8, 2, SEG, MODE>), grid, dim3(256), 0, a.stream, a.scratch_mag, out, \
-                     nd, nr, strips, a.regs.edge, kA, kB, a.det_list, a.det_cap, a.det_count, ch0, tile)
+                     nd, nr, strips, a.regs.edge, kA, kB, a.det_list, a.det_cap, a.det_count, ch0, tile, a.regs, a.log2nr)
     if (a.regs.cfar_mode == 0) RSP_WALK(0);
     else if (a.regs.cfar_mode == 1) RSP_WALK(1);
     else RSP_WALK(2);
@@ -950,6 +975,20 @@ static hipError_t launch_rd2d_chunk_fx(const Rd2dLaunch& a, uint32_t ch0, uint32
   const size_t lds = 4 * ((size_t)(kTD + 2 * hd) * ((kTR + 2 * hr) | 1) +
                           (a.regs.cfar_mode ? 2 : 1) * ((size_t)(kTD + 2 * hd + 1) * (kTR + 1) + (size_t)(kTD + 2 * a.guard_d + 1) * (kTR + 1)));
   if (lds > 160 * 1024) return hipErrorInvalidValue;
+  const bool spec = a.regs.R == 8 && a.regs.G == 2 && a.ref_d == 8 && a.guard_d == 2;  // cfg 3 / cfg 5 windows: the strip walker
+  if (spec && !a.force_tiled_cfar) {
+    const uint32_t strips = (nr + walk_outw(10) - 1) / walk_outw(10);
+    constexpr uint32_t SEG = RSP_WALK_SEG;
+    const dim3 grid(n_ch * strips * (nd / SEG / 4));
+#define RSP_WALK(MODE)                                                                                                   \
+  hipLaunchKernelGGL((cfar2d_walk_kernel<8, 2, 8, 2, SEG, MODE, int32_t>), grid, dim3(256), 0, a.stream, mag, out, nd, nr, \
+                     strips, a.regs.edge, 0.f, 0.f, a.det_list, a.det_cap, a.det_count, ch0, tile, a.regs, a.log2nr)
+    if (a.regs.cfar_mode == 0) RSP_WALK(0);
+    else if (a.regs.cfar_mode == 1) RSP_WALK(1);
+    else RSP_WALK(2);
+#undef RSP_WALK
+    return hipGetLastError();
+  }
   auto k = cfar2d_kernel<-1, -1, -1, -1, int32_t>;
   static LdsGrant granted;
   e = grant_lds(k, lds, a.device, granted);

@@ -360,3 +360,19 @@ def test_rd2d_fused_list_overflow_and_chunks(gpu, scaler, chunk_mb):
     order = np.argsort(key)
     assert np.array_equal(key[order], (ch.astype(np.int64) * nd + d) * nr + r)
     assert np.array_equal(lst[order, 3], dense[ch, d, r])
+
+
+@pytest.mark.parametrize("mode", ["Cell Averaging", "Greatest Of", "Smallest Of"])
+def test_rd2d_fixed_walker_equals_tile_kernel(gpu, mode):
+    """FIXED16, the compile-time windows: the strip walker (integer instantiation) and the run-time-window tile kernel
+    give the oracle's words, both."""
+    nr, nd, n_ch = 1024, 256, 2
+    params = rd_params_fx(nr, nd, edge="wrap")
+    rt = R.RunTimeRspChainParams(fftSize=nr, CFARMode=mode, refWindowSize=8, guardWindowSize=2, divSum=8, thresholdScaler=2.0)
+    beats, _ = targets_fx(n_ch, nd, nr, seed=321)
+    ref = fx_oracle(params, rt, beats, nd, 8, 2)
+    for tiled in (0, 1):
+        with R.FftMagCfarChainVanilla(params) as dut:
+            dut.configure(rt)
+            dut.set_option(dut.FORCE_TILED_CFAR2D, tiled)
+            assert np.array_equal(dut.stream(beats), ref), tiled
