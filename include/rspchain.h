@@ -193,8 +193,11 @@ int rsp_chain_process_device(rsp_chain* c, const void* d_in_beats, size_t n_fram
  * d_out_words may be NULL: detection-list-only output (8 B read per cell, no dense
  * write); then a frame contributes at most RSP_FRAME_DET_CAP peaks (the kernel's
  * per-frame staging) and d_count[1] < d_count[0] tells when that limit hit.
+ * 1-D chain, list order: up to 16384 frames per call the frames appear in ascending order (a
+ * frame's peaks contiguous, in no particular order); above that only a frame's peaks stay contiguous.
  * 2-D chain: the CFAR kernel appends its peak cells to the list itself (dense words are
- * always written: d_out_words must not be NULL); list order is unspecified. */
+ * always written: d_out_words must not be NULL); d_count is also the list's cursor while the call
+ * runs (zeroed by its first kernel); list order is unspecified. */
 #define RSP_FRAME_DET_CAP 64
 int rsp_chain_process_detect_device(rsp_chain* c, const void* d_in_beats, size_t n_frames,
                                     uint32_t* d_out_words, rsp_detection* d_list, uint32_t cap,
