@@ -1,0 +1,303 @@
+// GOS / ordered-statistic CFAR tail of the fused 1-D chain (cfg 4).
+// GOSCFARType / GOSCACFARType with cfarAlgorithm = GOS (FftMagCfarChainTester.scala:105-127):
+// the per-side statistic is the indexLagg-th / indexLead-th smallest cell of the window.
+// The hardware keeps each window sorted with a linear insertion sorter; here every thread keeps
+// ONE sorted window in registers: it bitonic-sorts the R cells starting at its first window
+// start, then slides it (branch-free delete + insert, cmp/cndmask + med3 per element) over its
+// run of consecutive starts, writing the two order statistics of every start to LDS.  The
+// lagging window of cell k starts at k - G - R, the leading one at k + G + 1, so a cell needs two
+// lookups.  Starts run over [-(G+R), N + G]; cells outside the frame come from the magnitude
+// halo (zeros or the wrapped image).
+
+#pragma once
+#include "chain_front.hpp"
+
+namespace rsp {
+
+template <typename V> __device__ __forceinline__ V vmin(V a, V b) { return a < b ? a : b; }
+template <typename V> __device__ __forceinline__ V vmax(V a, V b) { return a > b ? a : b; }
+// fminf / fmaxf quiet their operands first (a v_max x, x each); magnitudes are never NaN, and v_med3 with an
+// infinity is the same selection in ONE instruction (the infinities sit in SGPRs)
+template <> __device__ __forceinline__ float vmin<float>(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, -__builtin_inff()); }
+template <> __device__ __forceinline__ float vmax<float>(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
+// the same for the selection network, where the compiler folds the med3-with-infinity back into v_min / v_max and
+// canonicalises both operands first (3 instructions per selection): the bare instruction
+template <typename V> __device__ __forceinline__ V vmin1(V a, V b) { return a < b ? a : b; }
+template <typename V> __device__ __forceinline__ V vmax1(V a, V b) { return a > b ? a : b; }
+template <> __device__ __forceinline__ float vmin1<float>(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+template <> __device__ __forceinline__ float vmax1<float>(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// median of three, a <= c guaranteed by the caller
+template <typename V> __device__ __forceinline__ V vmed3(V a, V b, V c) { return vmin(vmax(a, b), c); }
+template <> __device__ __forceinline__ float vmed3<float>(float a, float b, float c) {
+  return __builtin_amdgcn_fmed3f(a, b, c);
+}
+
+// The sorted window lives in ONE vector value (R consecutive VGPRs): every access below has a
+// compile-time index except the order-statistic pick, which the compiler then lowers to an indexed
+// register read (s_set_gpr_idx_on + v_mov: 3 instructions) -- the index-th register, wave-uniform.
+// With a plain C array the same pick became a scratch-memory copy (4x slower) or, blended by hand,
+// log2(R) levels of v_bfi (31 instructions per pick at R = 32).
+template <typename V, int R> struct WinVec { typedef V type __attribute__((ext_vector_type(R))); };
+
+// Batcher's odd-even merge sort, ascending: 191 compare-exchanges at R = 32 (bitonic: 240), 543 at R = 64 (672);
+// every index is a compile-time constant after unrolling
+template <typename V, int R>
+__device__ __forceinline__ void sort_window(typename WinVec<V, R>::type& s) {
+#pragma unroll
+  for (int p = 1; p < R; p <<= 1) {
+#pragma unroll
+    for (int k = p; k >= 1; k >>= 1) {
+#pragma unroll
+      for (int j = k % p; j <= R - 1 - k; j += 2 * k) {
+#pragma unroll
+        for (int i = 0; i <= (k - 1 < R - j - k - 1 ? k - 1 : R - j - k - 1); ++i) {
+          if ((i + j) / (2 * p) == (i + j + k) / (2 * p)) {
+            const V a = s[i + j], b = s[i + j + k];
+            s[i + j] = vmin(a, b);
+            s[i + j + k] = vmax(a, b);
+          }
+        }
+      }
+    }
+  }
+}
+
+// lane mask of a < b into an SGPR pair / select by such a mask.  Inline asm: the compiler pairs every compare
+// with its select through VCC (one register: compare i+1 cannot start before select i has read it) and pads
+// each pair with s_nop 1 for the VALU-writes-mask hazard; batches of 8 explicit masks need no padding.
+__device__ __forceinline__ unsigned long long cmp_lt_mask(float a, float b) {
+  unsigned long long m;
+  asm volatile("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+  return m;
+}
+__device__ __forceinline__ unsigned long long cmp_lt_mask(int a, int b) {
+  unsigned long long m;
+  asm volatile("v_cmp_lt_i32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+  return m;
+}
+template <typename V>
+__device__ __forceinline__ V select_mask(unsigned long long m, V if_set, V if_clear) {
+  V r;
+  asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+  return r;
+}
+
+// sorted s: remove one element equal to `old`, insert `nw`, stay sorted
+template <typename V, int R>
+__device__ __forceinline__ void slide(typename WinVec<V, R>::type& s, V old, V nw) {
+  V t[R - 1];
+#pragma unroll
+  for (int b0 = 0; b0 < R - 1; b0 += 8) {
+    unsigned long long m[8];
+#pragma unroll
+    for (int i = b0; i < b0 + 8 && i < R - 1; ++i) {
+      const V a = s[i];
+      m[i - b0] = cmp_lt_mask(a, old);
+    }
+    if (R - 1 - b0 < 3) asm volatile("s_nop 1");  // a short last batch: keep 2 wait states between mask and select
+#pragma unroll
+    for (int i = b0; i < b0 + 8 && i < R - 1; ++i) {
+      const V a = s[i], b = s[i + 1];
+      t[i] = select_mask<V>(m[i - b0], a, b);
+    }
+  }
+  s[0] = vmin(t[0], nw);
+#pragma unroll
+  for (int i = 1; i < R - 1; ++i) s[i] = vmed3(t[i - 1], nw, t[i]);
+  s[R - 1] = vmax(t[R - 2], nw);
+}
+
+#ifndef RSP_GOS_SPLIT
+#define RSP_GOS_SPLIT 1
+#endif
+struct GosLayout {  // byte offsets inside a frame's LDS, computed on the host
+  int32_t frame_bytes, o1_off, o2_off, det_off, run;  // run = consecutive window starts per thread
+};
+
+template <typename V, int R>
+__device__ __forceinline__ void gos_stage(const V* mag, V* o1, V* o2, int tau, int run, int G,
+                                          int idx_lagg, int idx_lead) {
+  const int a0 = -(G + R) + run * tau;  // first window start of this thread
+  typename WinVec<V, R>::type s;
+#pragma unroll
+  for (int i = 0; i < R; ++i) s[i] = mag[pad(a0 + i + kHalo)];
+  sort_window<V, R>(s);
+  const bool two = idx_lagg != idx_lead;
+  for (int st = 0; st < run; ++st) {
+    const int oi = pad(run * tau + st);
+    o1[oi] = s[idx_lagg];
+    if (two) o2[oi] = s[idx_lead];
+    if (st + 1 < run) {
+      const V old = mag[pad(a0 + st + kHalo)], nw = mag[pad(a0 + st + R + kHalo)];
+      slide<V, R>(s, old, nw);
+    }
+  }
+}
+
+// k-th smallest (0-based, wave-uniform k) of a bitonic sequence of SZ = 2^n values: a half-cleaner per level leaves
+// the SZ/2 smallest (min side) or largest (max side) as a bitonic sequence again, so only the side that holds rank k
+// is computed: SZ - 1 min / max operations in all, every index a compile-time constant, the side a scalar branch.
+template <int SZ, typename V>
+__device__ __forceinline__ V select_bitonic(const V (&x)[SZ], int k) {
+  if constexpr (SZ == 1) {
+    return x[0];
+  } else {
+    V h[SZ / 2];
+    if (k & (SZ / 2)) {
+#pragma unroll
+      for (int i = 0; i < SZ / 2; ++i) h[i] = vmax1(x[i], x[i + SZ / 2]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < SZ / 2; ++i) h[i] = vmin1(x[i], x[i + SZ / 2]);
+    }
+    return select_bitonic<SZ / 2, V>(h, k);
+  }
+}
+
+// The same statistics with the window SPLIT: the RUN windows of a thread (starts a0 .. a0 + RUN - 1) all contain
+// the cells B = [a0 + RUN - 1, a0 + R); only the other RUN - 1 cells D change from start to start (one leaves at
+// the front, one enters past B).  B is sorted once, D is kept sorted with the delete + insert slide -- 3 (RUN - 1)
+// operations per start instead of 3 R -- and the order statistic is selected from the bitonic sequence
+// [B ascending | D descending] with R - 1 min / max.  R = 32, RUN = 17: two 16-element sorts + 16 x 48 + 17 x 31 =
+// 1547 operations per 17 starts against 382 + 16 x 94 = 1886 with one 32-cell sorted window.
+template <typename V, int R, int RUN>
+__device__ __forceinline__ void gos_stage_split(const V* mag, V* o1, V* o2, int tau, int G, int idx_lagg, int idx_lead) {
+  constexpr int ND = RUN - 1, NB = R - ND;
+  static_assert(NB >= 1 && (R & (R - 1)) == 0, "a common part and a power-of-two window");
+  const int a0 = -(G + R) + RUN * tau;  // first window start of this thread
+  typename WinVec<V, ND>::type d;
+  typename WinVec<V, NB>::type b;
+#pragma unroll
+  for (int i = 0; i < ND; ++i) d[i] = mag[pad(a0 + i + kHalo)];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) b[i] = mag[pad(a0 + ND + i + kHalo)];
+  sort_window<V, ND>(d);
+  sort_window<V, NB>(b);
+  const bool two = idx_lagg != idx_lead;
+#pragma unroll 1
+  for (int st = 0; st < RUN; ++st) {
+    V seq[R];  // [B ascending | D descending]
+#pragma unroll
+    for (int i = 0; i < NB; ++i) seq[i] = b[i];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) seq[NB + i] = d[ND - 1 - i];
+    int k1 = idx_lagg, k2 = idx_lead;
+    asm volatile("" : "+s"(k1), "+s"(k2));  // keep the five side branches inside the loop (no 32-way unswitching)
+    const int oi = pad(RUN * tau + st);
+    o1[oi] = select_bitonic<R, V>(seq, k1);
+    if (two) o2[oi] = select_bitonic<R, V>(seq, k2);
+    if (st + 1 < RUN) {
+      const V old = mag[pad(a0 + st + kHalo)], nw = mag[pad(a0 + st + R + kHalo)];
+      slide<V, ND>(d, old, nw);
+    }
+  }
+}
+
+// BIG = the 64-cell window: its sorted window alone is 64 + 63 registers, so it is a kernel of its own -- as one path
+// of a common kernel it set the register count (141 + scratch) and with it the occupancy (one 512-thread workgroup
+// per CU at 8192 points) of every other window size.
+template <int M, bool FIXED, bool BIG, int FX>
+__global__ void __launch_bounds__(wg_size(M))
+chain1d_gos_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t n_frames,
+                   ChainRegs rg, GosLayout lay, const void* __restrict__ tw,
+                   const int16_t* __restrict__ log_lut, uint32_t* __restrict__ fcount,
+                   uint2* __restrict__ fdet) {
+  constexpr int N = 1 << M, T = threads_per_frame(M), FPW = frames_per_wg(M);
+  using V = typename std::conditional<FIXED, int, float>::type;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int fl = tid / T, tau = tid % T;
+  const uint32_t frame = blockIdx.x * FPW + fl;
+  const bool live = frame < n_frames;
+  unsigned char* fbase = smem + (size_t)fl * lay.frame_bytes;
+
+  V mg[16];
+  SideHooks hk;
+  hk.init(rg);
+  front_end<M, FIXED, V, FX>(in, frame, live, tau, fbase, rg, tw, log_lut,
+                             reinterpret_cast<uint32_t*>(smem + (size_t)lay.frame_bytes * FPW), mg, hk);
+
+  V* mag = reinterpret_cast<V*>(fbase);  // cell x in [-256, N + 256] at slot pad(x + 256)
+  V* o1 = reinterpret_cast<V*>(fbase + lay.o1_off);
+  V* o2 = reinterpret_cast<V*>(fbase + lay.o2_off);
+  uint32_t* det_cnt = reinterpret_cast<uint32_t*>(fbase + lay.det_off);
+  uint2* det_stage = reinterpret_cast<uint2*>(fbase + lay.det_off + 8);
+  const bool wrap = rg.edge != 0;
+  __syncthreads();  // every thread is done reading the FFT image this overlays
+  write_mag<M, V>(mag, kHalo, tau, mg, rg.rev_order != 0);
+  if (tau == 0) *det_cnt = 0u;
+  __syncthreads();
+  for (int h = tau; h < 32; h += T) {  // halos: 32 runs of 16 cells, zeros or the wrapped image
+    const int x0 = h < 16 ? -kHalo + 16 * h : N + 16 * (h - 16);
+    const int src = h < 16 ? x0 + N : x0 - N;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mag[pad(x0 + e + kHalo)] = wrap ? mag[pad(src + e + kHalo)] : V(0);
+    if (h == 31) mag[pad(N + kHalo + kHalo)] = wrap ? mag[pad(kHalo + kHalo)] : V(0);
+  }
+  __syncthreads();
+  if constexpr (BIG) {
+    if (lay.run == 17 && RSP_GOS_SPLIT) gos_stage_split<V, 64, 17>(mag, o1, o2, tau, rg.G, rg.idx_lagg, rg.idx_lead);
+    else gos_stage<V, 64>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead);
+  } else {
+    switch (rg.R) {
+      case 4: gos_stage<V, 4>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead); break;
+      case 8: gos_stage<V, 8>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead); break;
+      case 16: gos_stage<V, 16>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead); break;
+      default:
+        if (lay.run == 17 && RSP_GOS_SPLIT) gos_stage_split<V, 32, 17>(mag, o1, o2, tau, rg.G, rg.idx_lagg, rg.idx_lead);
+        else gos_stage<V, 32>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead);
+        break;
+    }
+  }
+  __syncthreads();
+
+  // cell k = tau + T j: lagging statistic = o1[k] (window start k - G - R), leading = o2[k + 2G + R + 1]
+  uint32_t word[16];
+  {
+    constexpr int JS = T + T / 16;
+    const V* pl = o1 + pad(tau);
+    const V* pr = o2 + pad(tau + 2 * rg.G + rg.R + 1);
+    const V* pm = mag + pad(tau + kHalo);
+    const int dl = ((tau & 15) == 0) ? 2 : 1, dr = ((tau & 15) == 15) ? 2 : 1;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const V a = pl[JS * j], b = pr[JS * j];
+      V stat;
+      if (rg.cfar_mode == 0) stat = CfarMath<V>::half_sum(a, b);
+      else if (rg.cfar_mode == 1) stat = a > b ? a : b;
+      else stat = a < b ? a : b;
+      const V cut = pm[JS * j];
+      bool group_ok = true;
+      if (rg.peak_grouping) group_ok = cut > pm[JS * j - dl] && cut > pm[JS * j + dr];
+      word[j] = CfarMath<V>::finish(stat, cut, group_ok, tau + T * j, M, rg);
+    }
+  }
+  emit_words<M, V>(word, out, frame, live, tau, det_cnt, det_stage, fcount, fdet,
+                   rg.send_cut ? mag + pad(tau + kHalo) : nullptr, T + T / 16);
+}
+
+// GOS kernel LDS: magnitude with 256-cell halos + one or two order-statistic arrays + staging
+template <int M>
+static GosLayout gos_layout(const ChainRegs& rg) {
+  constexpr int N = 1 << M, T = threads_per_frame(M);
+  GosLayout l;
+  l.run = (N + 2 * rg.G + rg.R + 1 + T - 1) / T;
+  const int mag_bytes = 4 * (pad_slots(N + 2 * kHalo) + 2);
+  const int o_bytes = 4 * (pad_slots(l.run * T) + 2);
+  l.o1_off = mag_bytes;
+  l.o2_off = rg.idx_lagg != rg.idx_lead ? l.o1_off + o_bytes : l.o1_off;
+  l.det_off = (l.o2_off + o_bytes + 7) & ~7;
+  const int total = l.det_off + 8 + 8 * kFrameDetCap;
+  l.frame_bytes = ((total > FrameLds<M>::FFT_BYTES ? total : FrameLds<M>::FFT_BYTES) + 15) & ~15;
+  return l;
+}
+
+}  // namespace rsp

@@ -29,6 +29,7 @@
 #include <type_traits>
 
 #include "chain_regs.hpp"
+#include "side_build.hpp"
 
 namespace rsp {
 
@@ -285,45 +286,70 @@ struct TwAll {
   }
 };
 
-// Whole F32 FFT of one frame through the LDS image `buf`.  load(d) returns the sample at the
-// thread's first sample index + d (d is a compile-time constant after unrolling, so the caller's
-// address arithmetic folds into immediates).  On return x[g 2^WL + p] holds, unscaled, bin
-// (bitrev(p) << (M - WL)) | (g T + tau), WL = width of the last pass.
+// Whole F32 FFT of one frame through the LDS image `buf`, in two halves so that a caller may touch the
+// samples between them (pre-FFT window):
+//   fft_f32_load    all passes' base twiddles, then the thread's 16 samples: load(d) returns the sample at
+//                   the thread's first sample index + d (d is a compile-time constant after unrolling, so
+//                   the caller's address arithmetic folds into immediates);
+//   fft_f32_passes  the register passes and their LDS exchanges.  On return x[g 2^WL + p] holds,
+//                   unscaled, bin (bitrev(p) << (M - WL)) | (g T + tau), WL = width of the last pass.
+// `hk` = side-build hooks (side_build.hpp): ablation switches and phase stamps, empty in the product.
 template <int M, typename Load>
-__device__ __forceinline__ void fft_f32_frame(Load load, int tau, f32x2* buf,
-                                              const f32x2* __restrict__ tw, f32x2 (&x)[16]) {
-  constexpr int NP = plan_np(M);
-  TwAll<M> twb;
+__device__ __forceinline__ void fft_f32_load(Load load, int tau, const f32x2* __restrict__ tw, TwAll<M>& twb,
+                                             f32x2 (&x)[16]) {
   twb.load(tau, tw);
-  {
-    constexpr int W = plan_w(M, 0), LO = plan_lo(M, 0);
+  constexpr int W = plan_w(M, 0), LO = plan_lo(M, 0);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) x[e] = load(elem_index<M, LO, W>(0, e) - elem_index<M, LO, W>(0, 0));
-  }
-  pass_f32<M, 0>(x, twb.template get<0>());
-  auto exchange = [&](auto pc) {
-    constexpr int P = decltype(pc)::value;
-    constexpr int W0 = plan_w(M, P - 1), LO0 = plan_lo(M, P - 1);
-    constexpr int W1 = plan_w(M, P), LO1 = plan_lo(M, P);
-    constexpr bool LAST = P == NP - 1;
+  for (int e = 0; e < 16; ++e) x[e] = load(elem_index<M, LO, W>(0, e) - elem_index<M, LO, W>(0, 0));
+}
+
+// one exchange through the LDS image + the register pass behind it
+template <int M, int P, typename Hooks>
+__device__ __forceinline__ void fft_f32_exchange(int tau, f32x2* buf, const TwAll<M>& twb, f32x2 (&x)[16], Hooks& hk) {
+  constexpr int NP = plan_np(M);
+  constexpr int W0 = plan_w(M, P - 1), LO0 = plan_lo(M, P - 1);
+  constexpr int W1 = plan_w(M, P), LO1 = plan_lo(M, P);
+  constexpr bool LAST = P == NP - 1;
+  if (!hk.off(3)) {
 #pragma unroll
     for (int g = 0; g < (16 >> W0); ++g) {
       f32x2* b0 = buf + slot_base<M, LO0, W0, LAST>(tau, g);
 #pragma unroll
       for (int r = 0; r < (1 << W0); ++r) b0[slot_delta<M, LO0, W0>(r)] = x[g * (1 << W0) + r];
     }
-    __syncthreads();
+  }
+  __syncthreads();
+  if (!hk.off(3)) {
 #pragma unroll
     for (int g = 0; g < (16 >> W1); ++g) {
       const f32x2* b1 = buf + slot_base<M, LO1, W1, LAST>(tau, g);
 #pragma unroll
       for (int r = 0; r < (1 << W1); ++r) x[g * (1 << W1) + r] = b1[slot_delta<M, LO1, W1>(r)];
     }
-    pass_f32<M, P>(x, twb.template get<P>());
-  };
-  exchange(std::integral_constant<int, 1>{});
-  if constexpr (NP > 2) exchange(std::integral_constant<int, 2>{});
-  if constexpr (NP > 3) exchange(std::integral_constant<int, 3>{});
+  }
+  hk.stamp(2 * P + 1);
+  if (!hk.off(0)) pass_f32<M, P>(x, twb.template get<P>());
+  hk.stamp(2 * P + 2);
+}
+
+template <int M, typename Hooks>
+__device__ __forceinline__ void fft_f32_passes(int tau, f32x2* buf, const TwAll<M>& twb, f32x2 (&x)[16], Hooks& hk) {
+  constexpr int NP = plan_np(M);
+  hk.stamp(1);
+  if (!hk.off(0)) pass_f32<M, 0>(x, twb.template get<0>());
+  hk.stamp(2);
+  fft_f32_exchange<M, 1>(tau, buf, twb, x, hk);
+  if constexpr (NP > 2) fft_f32_exchange<M, 2>(tau, buf, twb, x, hk);
+  if constexpr (NP > 3) fft_f32_exchange<M, 3>(tau, buf, twb, x, hk);
+}
+
+template <int M, typename Load>
+__device__ __forceinline__ void fft_f32_frame(Load load, int tau, f32x2* buf,
+                                              const f32x2* __restrict__ tw, f32x2 (&x)[16]) {
+  TwAll<M> twb;
+  NoHooks hk;
+  fft_f32_load<M>(load, tau, tw, twb, x);
+  fft_f32_passes<M>(tau, buf, twb, x, hk);
 }
 
 // sample offset (from the thread's first sample) of register e before pass 0

@@ -30,7 +30,6 @@ struct Chain1dLaunch {
 
 hipError_t launch_chain1d(const Chain1dLaunch& a);
 hipError_t launch_chain1d_small(const Chain1dLaunch& a);  // 16..128-point frames (small.hip)
-size_t chain1d_lds_bytes(int log2n);
 
 // 2-D range-Doppler chain (rd2d.hip): in [n_ch][nd][nr] complex64 -> out [n_ch][nd][nr] words
 struct Rd2dLaunch {

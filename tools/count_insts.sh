@@ -6,7 +6,7 @@ set -e
 R=$(cd "$(dirname "$0")/.." && pwd); T=$(mktemp -d /tmp/rspcnt.XXXX); cd $T
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-function -DRSP_COUNT_PATH --cuda-device-only -S \
   $R/rsp-chains_amd/csrc/chain1d.hip -o k.s 2>/dev/null
-for K in _ZN3rsp14chain1d_kernelILi12ELb0EEE _ZN3rsp19chain1d_quad_kernelILi12ELb0EEE; do
+for K in _ZN3rsp14chain1d_kernelILi12ELb0E _ZN3rsp19chain1d_quad_kernelILi12ELb0E; do
   awk -v k="^$K.*:" '$0 ~ k {f=1} f{print} f&&/s_endpgm/{exit}' k.s > body.s
   echo "== $K"
   python3 - <<PY
