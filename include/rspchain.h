@@ -181,7 +181,11 @@ int rsp_chain_check_regs(rsp_chain* c);
  * words per cell, {the word described above, the cell under test} (FIXED16: the magnitude as a
  * sign-extended integer; F32: its fp32 bits) -- out_words then holds 2 x fftSize words per frame.
  * FFTParams.useBitReverse = false: the FFT block streams its result in bit-reversed order and the
- * blocks behind it work on that order; position p of a frame then refers to bin bitrev(p). */
+ * blocks behind it work on that order; position p of a frame then refers to bin bitrev(p).
+ * The batch moves as a pipeline of chunks -- H2D(k + 1) || kernels(k) || D2H(k - 1) on three streams.  Buffers
+ * from rsp_host_alloc, or pinned with rsp_host_register, are DMA'd in place at the link's rate; pageable
+ * memory (a plain malloc / JVM direct buffer / numpy array) is staged through a ring of pinned chunks by a pool
+ * of copy threads.  Results are identical either way. */
 int rsp_chain_process(rsp_chain* c, const void* in_beats, size_t n_frames, uint32_t* out_words);
 /* Same with buffers already resident in HBM; asynchronous on the chain's stream. */
 int rsp_chain_process_device(rsp_chain* c, const void* d_in_beats, size_t n_frames,
@@ -217,6 +221,8 @@ enum {
   RSP_OPT_MAX_FRAMES_PER_LAUNCH = 1, /* split a call into launches of at most this many frames (0 = automatic) */
   RSP_OPT_FORCE_TILED_CFAR2D = 2,    /* 2-D chain: run-time-window CFAR kernel even for the compile-time windows */
   RSP_OPT_FORCE_GENERIC_TAIL = 3,    /* 1-D chain: per-cell CFAR tail even where the 16-byte "quad" tail applies */
+  RSP_OPT_EXPERIMENT = 5,            /* A/B runs: 1 = hand 1-D launches to the experimental kernel of a side library built from tools/experiments/ (no effect on the product library) */
+  RSP_OPT_HOST_CHUNK_BYTES = 6,      /* host-buffer entries: input bytes per chunk of the H2D || kernel || D2H pipeline (0 = automatic, ~16 MiB) */
   RSP_OPT_RD_CHUNK_BYTES = 4         /* 2-D chain: bytes of intermediates (12 B/cell) per chunk of channels; 0 = whole batch (default: chunks of 48-192 MiB measured 0-60 % slower) */
 };
 int rsp_chain_set_option(rsp_chain* c, int option, int64_t value);
@@ -237,6 +243,12 @@ int rsp_chain_profile_read(rsp_chain* c, float* total_ms, uint32_t* launches);
 int rsp_device_count(int* n);
 int rsp_device_malloc(int device, void** ptr, size_t bytes);
 int rsp_device_free(int device, void* ptr);
+/* Pinned (page-locked) host memory for the host-buffer entry points: allocate the stream buffers here, or pin
+ * caller-owned memory for as long as it is used with the chain (unregister it BEFORE freeing it). */
+int rsp_host_alloc(int device, void** ptr, size_t bytes);
+int rsp_host_free(void* ptr);
+int rsp_host_register(int device, void* ptr, size_t bytes);
+int rsp_host_unregister(void* ptr);
 int rsp_memcpy_h2d(int device, void* dst, const void* src, size_t bytes);
 int rsp_memcpy_d2h(int device, void* dst, const void* src, size_t bytes);
 

@@ -8,7 +8,7 @@ creating a chain does not.
 from . import _native
 from .chain import (  # noqa: F401
     AddressSet, CACFARType, CFARParams, DeviceBuffer, F32, FFTParams, FIXED16, FixedNCOParams, FixedPLFGParams,
-    FftMagCfarChainVanilla, FftMagCfarVanillaParameters, FixedPoint, GOSCACFARType, GOSCFARType,
+    FftMagCfarChainVanilla, FftMagCfarVanillaParameters, FixedPoint, HostBuffer, GOSCACFARType, GOSCFARType,
     MAGParams, RspChainVanilla, RspChainVanillaParameters, RspError, RunTimeRspChainParams, device_count, isPow2, log2Up, unpack_output,
     unpack_output_f32)
 from . import stimulus  # noqa: F401

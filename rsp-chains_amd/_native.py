@@ -103,6 +103,10 @@ SIGNATURES = {
     "rsp_device_count": (C.c_int, [_P(C.c_int)]),
     "rsp_device_malloc": (C.c_int, [C.c_int, _P(C.c_void_p), C.c_size_t]),
     "rsp_device_free": (C.c_int, [C.c_int, C.c_void_p]),
+    "rsp_host_alloc": (C.c_int, [C.c_int, _P(C.c_void_p), C.c_size_t]),
+    "rsp_host_free": (C.c_int, [C.c_void_p]),
+    "rsp_host_register": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t]),
+    "rsp_host_unregister": (C.c_int, [C.c_void_p]),
     "rsp_memcpy_h2d": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rsp_memcpy_d2h": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rsp_stimulus_default_params": (None, [_P(StimulusParamsC)]),

@@ -336,13 +336,20 @@ class FftMagCfarChainVanilla:
                              "(TLAST closes every frame)")
         return a
 
-    def stream(self, beats) -> np.ndarray:
+    def stream(self, beats, out: Optional[np.ndarray] = None) -> np.ndarray:
         """Enqueue whole frames (TLAST on each frame's final beat, Tester:137) and
-        collect fftSize output words per frame (Tester:145-151)."""
+        collect fftSize output words per frame (Tester:145-151).  `out`: a uint32 array to receive the words
+        (e.g. a HostBuffer's: pinned memory moves over the link in place, include/rspchain.h)."""
         a = self._as_beats(beats)
         n = self.frameCells
         cut = bool(self.params.cfarParams.sendCut)   # 64-bit output beat: {word, cut} per cell
-        out = np.empty(a.size * (2 if cut else 1), np.uint32)
+        words = a.size * (2 if cut else 1)
+        if out is None:
+            out = np.empty(words, np.uint32)
+        else:
+            if out.dtype != np.uint32 or out.size != words or not out.flags.c_contiguous:
+                raise ValueError(f"requirement failed: out must be a contiguous uint32 array of {words} words")
+            out = out.reshape(-1)
         _check(self._lib.rsp_chain_process(self._h, a.ctypes.data_as(C.c_void_p), a.size // n,
                                            out.ctypes.data_as(C.c_void_p)))
         if self.params.dopplerPoints:
@@ -378,7 +385,7 @@ class FftMagCfarChainVanilla:
         _check(self._lib.rsp_chain_detections_device(self._h, C.c_void_p(d_words), n_frames,
                                                      C.c_void_p(d_list), cap, C.c_void_p(d_count)))
 
-    MAX_FRAMES_PER_LAUNCH, FORCE_TILED_CFAR2D, FORCE_GENERIC_TAIL, RD_CHUNK_BYTES = 1, 2, 3, 4   # RSP_OPT_* of include/rspchain.h
+    MAX_FRAMES_PER_LAUNCH, FORCE_TILED_CFAR2D, FORCE_GENERIC_TAIL, RD_CHUNK_BYTES, EXPERIMENT, HOST_CHUNK_BYTES = 1, 2, 3, 4, 5, 6   # RSP_OPT_* of include/rspchain.h
 
     def set_option(self, option: int, value: int):
         _check(self._lib.rsp_chain_set_option(self._h, option, value))
@@ -595,6 +602,32 @@ def device_count() -> int:
     n = C.c_int()
     rc = N.lib().rsp_device_count(C.byref(n))
     return n.value if rc == 0 else 0
+
+
+class HostBuffer:
+    """Pinned host memory from rsp_host_alloc, viewed as a NumPy array: stream buffers the host-buffer entry
+    points DMA in place (the JVM-side counterpart wraps the same allocation in a direct ByteBuffer)."""
+
+    def __init__(self, shape, dtype, device: int = 0):
+        self.dtype = np.dtype(dtype)
+        self.shape = tuple(np.atleast_1d(shape))
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self._p = C.c_void_p()
+        _check(N.lib().rsp_host_alloc(device, C.byref(self._p), self.nbytes))
+        buf = (C.c_char * self.nbytes).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=self.dtype).reshape(self.shape)
+
+    def free(self):
+        if self._p:
+            self.array = None
+            N.lib().rsp_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class DeviceBuffer:

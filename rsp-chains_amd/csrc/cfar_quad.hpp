@@ -82,16 +82,12 @@ __device__ __forceinline__ V seg_scan(V v) {
   return v;
 }
 
-// workgroup barrier of the tail: the plain kernels use __syncthreads(); the pipelined kernel (chain1d_pipe.hip)
-// keeps LDS-DMA loads in flight across the tail and brings its own (no vector-memory wait)
-struct PlainBarrier {
-  static __device__ __forceinline__ void sync() { __syncthreads(); }
-};
-
 // The tail proper: mg[] (front_end's register order) -> magnitude image -> scan -> cells -> dense words to HBM
 // (+ per-frame detection slots).  `fbase` = the frame's LDS (QuadLds<M, SMALL>), free to be overwritten once
-// every thread has passed the first barrier below.
-template <int M, bool FIXED, bool SMALL, typename Barrier, typename V, typename Hooks>
+// every thread has passed the first barrier below.  Barriers are the hook policy's (Hooks::barrier(): __syncthreads()
+// in the plain kernels; the pipelined kernel of chain1d_pipe.hip keeps LDS-DMA loads in flight across the tail and
+// brings a barrier without a vector-memory wait).
+template <int M, bool FIXED, bool SMALL, typename V, typename Hooks>
 __device__ __forceinline__ void quad_tail(unsigned char* fbase, const V (&mg)[16], int tau, uint32_t frame, bool live,
                                           const ChainRegs& rg, uint32_t* __restrict__ out,
                                           uint32_t* __restrict__ fcount, uint2* __restrict__ fdet, Hooks& hk) {
@@ -108,7 +104,7 @@ __device__ __forceinline__ void quad_tail(unsigned char* fbase, const V (&mg)[16
   uint32_t* det_cnt = reinterpret_cast<uint32_t*>(fbase + L::DET_OFF);
   uint2* det_stage = reinterpret_cast<uint2*>(fbase + L::DET_OFF + 8);
   const bool wrap = rg.edge != 0;
-  Barrier::sync();  // every thread is done reading the FFT image this overlays
+  Hooks::barrier();  // every thread is done reading the FFT image this overlays
   {  // magnitudes to LDS in natural bin order: register (g, p) holds bin (bitrev(p) << (M - WL)) | (g T + tau)
     constexpr int NP = plan_np(M), WL = plan_w(M, NP - 1);
     if (rg.rev_order) {  // useBitReverse = false: bin b at stream position bitrev(b) = (bitrev(g T + tau) << WL) | p
@@ -131,7 +127,7 @@ __device__ __forceinline__ void quad_tail(unsigned char* fbase, const V (&mg)[16
     *det_cnt = 0u;
     bs[N / 256 + 1] = V(0);  // the "no block total" slot of the window fix-ups
   }
-  Barrier::sync();
+  Hooks::barrier();
   hk.stamp(8);
 
   // ---- scan: block-relative exclusive prefix sums of the thread's 4 quads ----
@@ -194,7 +190,7 @@ __device__ __forceinline__ void quad_tail(unsigned char* fbase, const V (&mg)[16
         if (((tau + T * e) & 63) == 63) block_total(e);
     }
   }
-  Barrier::sync();
+  Hooks::barrier();
 
   hk.stamp(9);
   // ---- CFAR on quads: cells k0 + i, k0 = 4 tau + 4 T e, i = 0..3 ----
@@ -310,6 +306,8 @@ __device__ __forceinline__ void quad_tail(unsigned char* fbase, const V (&mg)[16
           // took the FIXED16 kernel to 142 VGPRs (three workgroups per CU at 4096 points instead of four)
           __builtin_amdgcn_sched_barrier(0);
         }
+        // the pipelined kernel holds its prefetched samples (32 VGPRs) through the tail: quad by quad there too
+        if constexpr (!FIXED && Hooks::kSerialQuads) __builtin_amdgcn_sched_barrier(0);
       }
     };
     using I0 = std::integral_constant<int, 0>;
@@ -329,6 +327,7 @@ __device__ __forceinline__ void quad_tail(unsigned char* fbase, const V (&mg)[16
   }
 
   hk.stamp(10);
+  hk.before_stores();
   // ---- dense words: one 16-byte store per quad (1 KiB per wave-instruction) ----
   if (live && out && rg.send_cut) {  // sendCut = true: 64-bit beat {word, cut}, two 16-byte stores per quad
     char* obase = reinterpret_cast<char*>(out) + ((size_t)frame * N + 4u * (size_t)tau) * 8u;
@@ -371,7 +370,7 @@ __device__ __forceinline__ void quad_tail(unsigned char* fbase, const V (&mg)[16
       }
     }
     // per-frame detection slots (no global atomics): count + first kFrameDetCap peaks
-    Barrier::sync();
+    Hooks::barrier();
     if (live) {
       const uint32_t cnt = *det_cnt;
       if (tau == 0) fcount[frame] = cnt;
@@ -401,10 +400,11 @@ chain1d_quad_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uin
   SideHooks hk;
   hk.init(rg);
   hk.stamp(0);
-  front_end<M, FIXED, V, FX>(in, frame, live, tau, fbase, rg, tw, log_lut,
+// (side builds, -DRSP_ABLATE: mask bit 5 reads 64 L2-resident frames instead of the batch, bit 6 drops the word stores)
+  front_end<M, FIXED, V, FX>(in, hk.off(5) ? (frame & 63u) : frame, live, tau, fbase, rg, tw, log_lut,
                              reinterpret_cast<uint32_t*>(smem + (size_t)L::BYTES * FPW), mg, hk);
   hk.stamp(7);
-  quad_tail<M, FIXED, SMALL, PlainBarrier>(fbase, mg, tau, frame, live, rg, out, fcount, fdet, hk);
+  quad_tail<M, FIXED, SMALL>(fbase, mg, tau, frame, live, rg, hk.off(6) ? nullptr : out, fcount, fdet, hk);
 }
 
 }  // namespace rsp

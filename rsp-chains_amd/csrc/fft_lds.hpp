@@ -277,6 +277,17 @@ struct TwAll {
     if constexpr (plan_np(M) > 2) load_tw<M, 2>(tau, tw, p2);
     if constexpr (plan_np(M) > 3) load_tw<M, 3>(tau, tw, p3);
   }
+  // an empty asm statement that reads and "rewrites" every loaded register: the loads have completed behind it
+  __device__ __forceinline__ void touch() {
+    auto t = [](auto& b) {
+#pragma unroll
+      for (auto& g : b.w) {
+#pragma unroll
+        for (auto& v : g) asm volatile("" : "+v"(v));
+      }
+    };
+    t(p0); t(p1); t(p2); t(p3);
+  }
   template <int P>
   __device__ __forceinline__ const TwBase<M, P>& get() const {
     if constexpr (P == 0) return p0;
@@ -293,7 +304,9 @@ struct TwAll {
 //                   the caller's address arithmetic folds into immediates);
 //   fft_f32_passes  the register passes and their LDS exchanges.  On return x[g 2^WL + p] holds,
 //                   unscaled, bin (bitrev(p) << (M - WL)) | (g T + tau), WL = width of the last pass.
-// `hk` = side-build hooks (side_build.hpp): ablation switches and phase stamps, empty in the product.
+// `hk` = the kernel's hook policy (side_build.hpp): the workgroup barrier of the exchanges, a call-out behind
+// each exchange's barrier (the pipelined kernel issues its next frame's loads there), and the side builds'
+// ablation switches and phase stamps -- all empty / __syncthreads() in the plain product kernels.
 template <int M, typename Load>
 __device__ __forceinline__ void fft_f32_load(Load load, int tau, const f32x2* __restrict__ tw, TwAll<M>& twb,
                                              f32x2 (&x)[16]) {
@@ -310,6 +323,7 @@ __device__ __forceinline__ void fft_f32_exchange(int tau, f32x2* buf, const TwAl
   constexpr int W0 = plan_w(M, P - 1), LO0 = plan_lo(M, P - 1);
   constexpr int W1 = plan_w(M, P), LO1 = plan_lo(M, P);
   constexpr bool LAST = P == NP - 1;
+  hk.template before_exchange<P>();
   if (!hk.off(3)) {
 #pragma unroll
     for (int g = 0; g < (16 >> W0); ++g) {
@@ -318,7 +332,8 @@ __device__ __forceinline__ void fft_f32_exchange(int tau, f32x2* buf, const TwAl
       for (int r = 0; r < (1 << W0); ++r) b0[slot_delta<M, LO0, W0>(r)] = x[g * (1 << W0) + r];
     }
   }
-  __syncthreads();
+  Hooks::barrier();
+  hk.template after_exchange_barrier<P>();
   if (!hk.off(3)) {
 #pragma unroll
     for (int g = 0; g < (16 >> W1); ++g) {

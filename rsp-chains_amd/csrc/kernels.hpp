@@ -26,6 +26,7 @@ struct Chain1dLaunch {
   int device;                    // HIP ordinal the launch runs on (per-device one-time kernel attributes)
   uint32_t max_frames_per_launch;  // 0 = as many as 32-bit byte offsets allow; tests force the split path
   bool force_generic_tail;         // tests / A-B: per-cell CFAR tail even where the quad tail applies
+  bool experiment;                 // RSP_OPT_EXPERIMENT: hand the launch to a side library's kernel (tools/experiments/)
 };
 
 hipError_t launch_chain1d(const Chain1dLaunch& a);

@@ -15,6 +15,7 @@
 #include "../../include/rspchain.h"
 #include "chain_regs.hpp"
 #include "fft_lds.hpp"
+#include "host_pipe.hpp"
 #include "kernels.hpp"
 
 namespace {
@@ -93,7 +94,11 @@ struct rsp_chain {
   uint32_t opt_max_frames = 0;
   bool opt_force_tiled = false;
   bool opt_generic_tail = false;
+  bool opt_experiment = false;
   size_t opt_rd_chunk_bytes = 0;  // 2-D chain: intermediates per chunk of channels (0 = whole batch: chunking measured slower)
+  size_t opt_host_chunk_bytes = 0;  // host-buffer entry: input bytes per pipeline chunk (0 = automatic)
+  rsp::HostPipe hp;               // streams / events / pinned staging ring of the host-buffer entry points
+  hipEvent_t ev_switch = nullptr; // rsp_chain_set_stream: the new stream waits for what the old one still holds
 };
 
 namespace {
@@ -422,25 +427,24 @@ size_t beat_bytes(const rsp_chain* c) { return c->p.dtype == RSP_DTYPE_F32 ? 8 :
 int launch_rd(rsp_chain* c, const void* d_in, size_t n_ch, uint32_t* d_out, rsp_detection* d_list = nullptr,
               uint32_t cap = 0, uint32_t* d_found = nullptr);
 
-int launch_dense(rsp_chain* c, const void* d_in, size_t n_frames, uint32_t* d_out,
-                 rsp_detection* d_list = nullptr, uint32_t cap = 0, uint32_t* d_found = nullptr) {
-  int rc = check_regs(c);
-  if (rc != RSP_OK) return rc;
-  if (c->p.dopplerPoints) return launch_rd(c, d_in, n_frames, d_out, d_list, cap, d_found);
-  if (n_frames > 0x7fffffffull) return fail(RSP_ERR_INVALID, "n_frames = %zu too large for one call", n_frames);
-  if (n_frames && (!d_in || (!d_out && !d_found))) return fail(RSP_ERR_INVALID, "NULL buffer");
-  HIP_TRY(hipSetDevice(c->device));
-  if (d_found && n_frames > c->fslots) {  // (re)size the per-frame slot buffers; not on the hot path
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->d_fcount) HIP_TRY(hipFree(c->d_fcount));
-    if (c->d_fdet) HIP_TRY(hipFree(c->d_fdet));
-    c->d_fcount = nullptr;
-    c->d_fdet = nullptr;
-    c->fslots = 0;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_fcount), n_frames * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_fdet), n_frames * rsp::kFrameDetCap * sizeof(uint2)));
-    c->fslots = n_frames;
-  }
+// per-frame slot buffers of the fused 1-D list: (re)sized outside the hot path
+int ensure_slots(rsp_chain* c, size_t n_frames) {
+  if (n_frames <= c->fslots) return RSP_OK;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->d_fcount) HIP_TRY(hipFree(c->d_fcount));
+  if (c->d_fdet) HIP_TRY(hipFree(c->d_fdet));
+  c->d_fcount = nullptr;
+  c->d_fdet = nullptr;
+  c->fslots = 0;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_fcount), n_frames * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_fdet), n_frames * rsp::kFrameDetCap * sizeof(uint2)));
+  c->fslots = n_frames;
+  return RSP_OK;
+}
+
+// The 1-D chain kernel over n_frames frames: dense words and / or the per-frame detection slots of frames
+// slot0 .. slot0 + n_frames (slot0 < 0: none).  No compaction: callers that cut a batch into chunks compact once.
+int launch_frames(rsp_chain* c, const void* d_in, size_t n_frames, uint32_t* d_out, int64_t slot0) {
   rsp::Chain1dLaunch a{};
   a.in = d_in;
   a.out = d_out;
@@ -448,7 +452,7 @@ int launch_dense(rsp_chain* c, const void* d_in, size_t n_frames, uint32_t* d_ou
   a.log2n = (int)c->fft_stages;
   a.fixed = c->p.dtype == RSP_DTYPE_FIXED16;
   a.regs = snapshot(c);
-  rc = get_rom(c, a.log2n, &a.twiddles);
+  int rc = get_rom(c, a.log2n, &a.twiddles);
   if (rc != RSP_OK) return rc;
   rc = get_window(c, c->p.window, a.log2n, &a.regs.window);
   if (rc != RSP_OK) return rc;
@@ -457,9 +461,10 @@ int launch_dense(rsp_chain* c, const void* d_in, size_t n_frames, uint32_t* d_ou
   a.device = c->device;
   a.max_frames_per_launch = c->opt_max_frames;
   a.force_generic_tail = c->opt_generic_tail;
-  if (d_found) {
-    a.frame_count = c->d_fcount;
-    a.frame_det = c->d_fdet;
+  a.experiment = c->opt_experiment;
+  if (slot0 >= 0) {
+    a.frame_count = c->d_fcount + slot0;
+    a.frame_det = c->d_fdet + (size_t)slot0 * rsp::kFrameDetCap;
   }
   hipEvent_t pe0 = nullptr, pe1 = nullptr;
   if (c->profiling) {
@@ -476,9 +481,36 @@ int launch_dense(rsp_chain* c, const void* d_in, size_t n_frames, uint32_t* d_ou
   }
   HIP_TRY(rsp::launch_chain1d(a));
   if (pe1) HIP_TRY(hipEventRecord(pe1, c->stream));
-  if (d_found)
-    HIP_TRY(rsp::launch_compact_frames(c->d_fcount, c->d_fdet, (uint32_t)n_frames, d_out, a.log2n, a.regs.send_cut,
-                                       d_list, cap, c->d_ctr, d_found, c->stream));
+  return RSP_OK;
+}
+
+// per-frame slots of frames 0 .. n_frames -> list; on a failed launch the shared counters are re-zeroed so that
+// the next call does not publish stale counts
+int launch_list(rsp_chain* c, size_t n_frames, uint32_t* d_out, rsp_detection* d_list, uint32_t cap, uint32_t* d_found) {
+  const hipError_t e = rsp::launch_compact_frames(c->d_fcount, c->d_fdet, (uint32_t)n_frames, d_out, (int)c->fft_stages,
+                                                  c->p.cfarParams.sendCut ? 1 : 0, d_list, cap, c->d_ctr, d_found, c->stream);
+  if (e != hipSuccess) {
+    (void)hipMemsetAsync(c->d_ctr, 0, rsp::kCompactCounters * sizeof(uint32_t), c->stream);
+    return fail(RSP_ERR_DEVICE, "detection compaction failed: %s", hipGetErrorString(e));
+  }
+  return RSP_OK;
+}
+
+int launch_dense(rsp_chain* c, const void* d_in, size_t n_frames, uint32_t* d_out,
+                 rsp_detection* d_list = nullptr, uint32_t cap = 0, uint32_t* d_found = nullptr) {
+  int rc = check_regs(c);
+  if (rc != RSP_OK) return rc;
+  if (c->p.dopplerPoints) return launch_rd(c, d_in, n_frames, d_out, d_list, cap, d_found);
+  if (n_frames > 0x7fffffffull) return fail(RSP_ERR_INVALID, "n_frames = %zu too large for one call", n_frames);
+  if (n_frames && (!d_in || (!d_out && !d_found))) return fail(RSP_ERR_INVALID, "NULL buffer");
+  HIP_TRY(hipSetDevice(c->device));
+  if (d_found) {
+    rc = ensure_slots(c, n_frames);
+    if (rc != RSP_OK) return rc;
+  }
+  rc = launch_frames(c, d_in, n_frames, d_out, d_found ? 0 : -1);
+  if (rc != RSP_OK) return rc;
+  if (d_found) return launch_list(c, n_frames, d_out, d_list, cap, d_found);
   return RSP_OK;
 }
 
@@ -543,6 +575,107 @@ int launch_rd(rsp_chain* c, const void* d_in, size_t n_ch, uint32_t* d_out, rsp_
   }
   HIP_TRY(rsp::launch_rd2d(a));
   if (pe1) HIP_TRY(hipEventRecord(pe1, c->stream));
+  return RSP_OK;
+}
+
+// The host-buffer entry points as a three-stage pipeline over chunks of frames (host_pipe.hpp):
+// H2D(k + 1) || kernels(k) || D2H(k - 1).  out_words = NULL: the dense words stay on the device (detection call).
+// want_list: one compaction over the whole batch at the end, into c->d_list / c->d_count.
+int host_process(rsp_chain* c, const void* in_beats, size_t n_frames, uint32_t* out_words, bool want_list, uint32_t cap) {
+  const bool rd = c->p.dopplerPoints != 0;
+  const size_t frame_cells = (size_t)(rd ? c->p.dopplerPoints : 1) << c->fft_stages;
+  const size_t cells = n_frames * frame_cells;
+  if (rd && cells > 0x7fffffffull) return fail(RSP_ERR_INVALID, "2-D chain: %zu channels too many for one call", n_frames);
+  const size_t fin = frame_cells * beat_bytes(c), fout = frame_cells * sizeof(uint32_t) * (c->p.cfarParams.sendCut ? 2 : 1);
+  int rc = ensure(&c->d_in, &c->d_in_bytes, n_frames * fin);
+  if (rc != RSP_OK) return rc;
+  rc = ensure(reinterpret_cast<void**>(&c->d_out), &c->d_out_bytes, n_frames * fout);
+  if (rc != RSP_OK) return rc;
+  if (want_list) {
+    size_t list_bytes = c->d_list_cap * sizeof(rsp_detection);
+    rc = ensure(reinterpret_cast<void**>(&c->d_list), &list_bytes, std::max<size_t>(cap, 1) * sizeof(rsp_detection));
+    if (rc != RSP_OK) return rc;
+    c->d_list_cap = list_bytes / sizeof(rsp_detection);
+    if (!rd) {
+      rc = ensure_slots(c, n_frames);
+      if (rc != RSP_OK) return rc;
+    }
+  }
+  rsp::HostPipe& hp = c->hp;
+  HIP_TRY(hp.init());
+  // chunk = ~16 MiB of input (whole frames; whole 64-frame workgroup rows when there are that many): long enough
+  // for the link to run at its rate, short enough that filling and draining the pipeline stays a small part of it
+  const size_t want_bytes = c->opt_host_chunk_bytes ? c->opt_host_chunk_bytes : (size_t(16) << 20);
+  size_t cf = std::max<size_t>(1, want_bytes / fin);
+  if (cf >= 64) cf &= ~size_t(63);
+  cf = std::min(cf, n_frames);
+  const size_t n_chunks = (n_frames + cf - 1) / cf;
+  HIP_TRY(hp.events(n_chunks));
+  const bool in_pinned = rsp::host_range_pinned(in_beats, n_frames * fin);
+  const bool out_pinned = out_words && rsp::host_range_pinned(out_words, n_frames * fout);
+  if (!in_pinned) HIP_TRY(hp.staging(true, cf * fin));
+  if (out_words && !out_pinned) HIP_TRY(hp.staging(false, cf * fout));
+  const char* hin = static_cast<const char*>(in_beats);
+  char* hout = reinterpret_cast<char*>(out_words);
+  char* din = static_cast<char*>(c->d_in);
+  char* dout = reinterpret_cast<char*>(c->d_out);
+  constexpr int kSlots = rsp::HostPipe::kSlots, kDrainLag = kSlots - 1;
+  auto drain = [&](size_t j) -> hipError_t {  // staged output of chunk j: pinned ring -> the caller's buffer
+    const size_t f0 = j * cf, nf = std::min(cf, n_frames - f0);
+    hipError_t e = hipEventSynchronize(hp.ev_out[j]);
+    if (e != hipSuccess) return e;
+    hp.copier().copy(hout + f0 * fout, hp.stage_out[j % kSlots], nf * fout);
+    return hipSuccess;
+  };
+  auto run = [&]() -> int {
+    for (size_t k = 0; k < n_chunks; ++k) {
+      const size_t f0 = k * cf, nf = std::min(cf, n_frames - f0);
+      if (in_pinned) {
+        HIP_TRY(hipMemcpyAsync(din + f0 * fin, hin + f0 * fin, nf * fin, hipMemcpyHostToDevice, hp.h2d));
+      } else {
+        void* st = hp.stage_in[k % kSlots];
+        if (k >= (size_t)kSlots) HIP_TRY(hipEventSynchronize(hp.ev_in[k - kSlots]));  // the slot's previous chunk has left it
+        hp.copier().copy(st, hin + f0 * fin, nf * fin);
+        HIP_TRY(hipMemcpyAsync(din + f0 * fin, st, nf * fin, hipMemcpyHostToDevice, hp.h2d));
+      }
+      HIP_TRY(hipEventRecord(hp.ev_in[k], hp.h2d));
+      HIP_TRY(hipStreamWaitEvent(c->stream, hp.ev_in[k], 0));
+      uint32_t* dk = reinterpret_cast<uint32_t*>(dout + f0 * fout);
+      const int r2 = rd ? launch_rd(c, din + f0 * fin, nf, dk, nullptr, 0, nullptr)
+                        : launch_frames(c, din + f0 * fin, nf, dk, want_list ? (int64_t)f0 : -1);
+      if (r2 != RSP_OK) return r2;
+      if (out_words) {
+        HIP_TRY(hipEventRecord(hp.ev_k[k], c->stream));
+        HIP_TRY(hipStreamWaitEvent(hp.d2h, hp.ev_k[k], 0));
+        if (out_pinned) {
+          HIP_TRY(hipMemcpyAsync(hout + f0 * fout, dk, nf * fout, hipMemcpyDeviceToHost, hp.d2h));
+        } else {
+          // slot k % kSlots was drained kSlots - kDrainLag = 1 iteration ago (below)
+          HIP_TRY(hipMemcpyAsync(hp.stage_out[k % kSlots], dk, nf * fout, hipMemcpyDeviceToHost, hp.d2h));
+          HIP_TRY(hipEventRecord(hp.ev_out[k], hp.d2h));
+          if (k >= (size_t)kDrainLag) HIP_TRY(drain(k - kDrainLag));
+        }
+      }
+    }
+    if (out_words && !out_pinned)
+      for (size_t j = n_chunks > (size_t)kDrainLag ? n_chunks - kDrainLag : 0; j < n_chunks; ++j) HIP_TRY(drain(j));
+    if (want_list) {
+      if (rd) {
+        HIP_TRY(rsp::launch_compact(c->d_out, cells, c->fft_stages, (uint32_t)ilog2(c->p.dopplerPoints), 0u, c->d_list, cap,
+                                    c->d_ctr, c->d_count, c->stream));
+      } else {
+        const int r3 = launch_list(c, n_frames, c->d_out, c->d_list, cap, c->d_count);
+        if (r3 != RSP_OK) return r3;
+      }
+    }
+    return RSP_OK;
+  };
+  rc = run();
+  // every stage is joined before the call returns, also on an error: the caller's buffers must not be in flight
+  const hipError_t e0 = hipStreamSynchronize(hp.h2d), e1 = hipStreamSynchronize(c->stream), e2 = hipStreamSynchronize(hp.d2h);
+  if (rc != RSP_OK) return rc;
+  if (e0 != hipSuccess || e1 != hipSuccess || e2 != hipSuccess)
+    return fail(RSP_ERR_DEVICE, "host pipeline: %s", hipGetErrorString(e0 != hipSuccess ? e0 : e1 != hipSuccess ? e1 : e2));
   return RSP_OK;
 }
 
@@ -667,6 +800,8 @@ void rsp_chain_destroy(rsp_chain* c) {
     (void)hipEventDestroy(pr.first);
     (void)hipEventDestroy(pr.second);
   }
+  c->hp.destroy();
+  if (c->ev_switch) (void)hipEventDestroy(c->ev_switch);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -741,19 +876,7 @@ int rsp_chain_process(rsp_chain* c, const void* in_beats, size_t n_frames, uint3
   HIP_TRY(hipSetDevice(c->device));
   if (n_frames > (c->p.dopplerPoints ? 0xffffull : 0x7fffffffull))
     return fail(RSP_ERR_INVALID, "n_frames = %zu too large for one call", n_frames);
-  const size_t cells = (n_frames * (size_t)(c->p.dopplerPoints ? c->p.dopplerPoints : 1)) << c->fft_stages;
-  if (c->p.dopplerPoints && cells > 0x7fffffffull) return fail(RSP_ERR_INVALID, "2-D chain: %zu channels too many for one call", n_frames);
-  const size_t in_bytes = cells * beat_bytes(c), out_bytes = cells * sizeof(uint32_t) * (c->p.cfarParams.sendCut ? 2 : 1);
-  rc = ensure(&c->d_in, &c->d_in_bytes, in_bytes);
-  if (rc != RSP_OK) return rc;
-  rc = ensure(reinterpret_cast<void**>(&c->d_out), &c->d_out_bytes, out_bytes);
-  if (rc != RSP_OK) return rc;
-  HIP_TRY(hipMemcpyAsync(c->d_in, in_beats, in_bytes, hipMemcpyHostToDevice, c->stream));
-  rc = launch_dense(c, c->d_in, n_frames, c->d_out);
-  if (rc != RSP_OK) return rc;
-  HIP_TRY(hipMemcpyAsync(out_words, c->d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  return RSP_OK;
+  return host_process(c, in_beats, n_frames, out_words, false, 0);
 }
 
 int rsp_chain_detections_device(rsp_chain* c, const uint32_t* d_out_words, size_t n_frames,
@@ -783,24 +906,12 @@ int rsp_chain_process_detections(rsp_chain* c, const void* in_beats, size_t n_fr
   if (n_frames > (c->p.dopplerPoints ? 0xffffull : 0x7fffffffull))
     return fail(RSP_ERR_INVALID, "n_frames = %zu too large for one call", n_frames);
   HIP_TRY(hipSetDevice(c->device));
-  const size_t cells = (n_frames * (size_t)(c->p.dopplerPoints ? c->p.dopplerPoints : 1)) << c->fft_stages;
-  if (c->p.dopplerPoints && cells > 0x7fffffffull) return fail(RSP_ERR_INVALID, "2-D chain: %zu channels too many for one call", n_frames);
-  rc = ensure(&c->d_in, &c->d_in_bytes, cells * beat_bytes(c));
-  if (rc != RSP_OK) return rc;
   // dense words are kept on the device: a frame with more than RSP_FRAME_DET_CAP peaks is completed
   // from them, so the host call never truncates a frame
-  rc = ensure(reinterpret_cast<void**>(&c->d_out), &c->d_out_bytes, cells * sizeof(uint32_t) * (c->p.cfarParams.sendCut ? 2 : 1));
-  if (rc != RSP_OK) return rc;
-  size_t list_bytes = c->d_list_cap * sizeof(rsp_detection);
-  rc = ensure(reinterpret_cast<void**>(&c->d_list), &list_bytes, std::max<size_t>(cap, 1) * sizeof(rsp_detection));
-  if (rc != RSP_OK) return rc;
-  c->d_list_cap = list_bytes / sizeof(rsp_detection);
-  HIP_TRY(hipMemcpyAsync(c->d_in, in_beats, cells * beat_bytes(c), hipMemcpyHostToDevice, c->stream));
-  rc = launch_dense(c, c->d_in, n_frames, c->d_out, c->d_list, (uint32_t)cap, c->d_count);
+  rc = host_process(c, in_beats, n_frames, nullptr, true, (uint32_t)cap);
   if (rc != RSP_OK) return rc;
   uint32_t counts[2] = {0, 0};  // {found, stored}
-  HIP_TRY(hipMemcpyAsync(counts, c->d_count, sizeof(counts), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemcpy(counts, c->d_count, sizeof(counts), hipMemcpyDeviceToHost));
   const size_t stored = std::min<size_t>(counts[1], cap);
   if (stored) HIP_TRY(hipMemcpy(list, c->d_list, stored * sizeof(rsp_detection), hipMemcpyDeviceToHost));
   std::sort(list, list + stored, [](const rsp_detection& a, const rsp_detection& b) {
@@ -825,9 +936,16 @@ int rsp_chain_set_option(rsp_chain* c, int option, int64_t value) {
     case RSP_OPT_FORCE_GENERIC_TAIL:
       c->opt_generic_tail = value != 0;
       return RSP_OK;
+    case RSP_OPT_EXPERIMENT:
+      c->opt_experiment = value != 0;
+      return RSP_OK;
     case RSP_OPT_RD_CHUNK_BYTES:
       if (value < 0) return fail(RSP_ERR_INVALID, "chunk bytes = %lld", (long long)value);
       c->opt_rd_chunk_bytes = (size_t)value;
+      return RSP_OK;
+    case RSP_OPT_HOST_CHUNK_BYTES:
+      if (value < 0) return fail(RSP_ERR_INVALID, "chunk bytes = %lld", (long long)value);
+      c->opt_host_chunk_bytes = (size_t)value;
       return RSP_OK;
     default:
       return fail(RSP_ERR_INVALID, "unknown option %d", option);
@@ -836,7 +954,16 @@ int rsp_chain_set_option(rsp_chain* c, int option, int64_t value) {
 
 int rsp_chain_set_stream(rsp_chain* c, void* hip_stream) {
   if (!c) return fail(RSP_ERR_INVALID, "chain is NULL");
-  c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+  hipStream_t ns = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+  if (ns != c->stream) {
+    // per-handle scratch (compaction counters, per-frame slots) assumes ONE stream in flight: what the old stream
+    // still holds is ordered in front of the new one's work
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->ev_switch) HIP_TRY(hipEventCreateWithFlags(&c->ev_switch, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c->ev_switch, c->stream));
+    HIP_TRY(hipStreamWaitEvent(ns, c->ev_switch, 0));
+  }
+  c->stream = ns;
   return RSP_OK;
 }
 
@@ -905,6 +1032,32 @@ int rsp_device_malloc(int device, void** ptr, size_t bytes) {
 int rsp_device_free(int device, void* ptr) {
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(hipFree(ptr));
+  return RSP_OK;
+}
+
+int rsp_host_alloc(int device, void** ptr, size_t bytes) {
+  if (!ptr) return fail(RSP_ERR_INVALID, "NULL argument");
+  *ptr = nullptr;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+  return RSP_OK;
+}
+
+int rsp_host_free(void* ptr) {
+  if (ptr) HIP_TRY(hipHostFree(ptr));
+  return RSP_OK;
+}
+
+int rsp_host_register(int device, void* ptr, size_t bytes) {
+  if (!ptr || !bytes) return fail(RSP_ERR_INVALID, "NULL / empty range");
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  return RSP_OK;
+}
+
+int rsp_host_unregister(void* ptr) {
+  if (!ptr) return fail(RSP_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipHostUnregister(ptr));
   return RSP_OK;
 }
 

@@ -3,7 +3,8 @@
 //   -DRSP_ABLATE      phase ablation (tools/ablate.sh, tools/pmc_ablate.sh): a run-time mask, read from
 //                     ChainRegs::sub_window (unused by the CA-family kernels; the API fills it from
 //                     RSP_ABLATE_MASK), switches phases off -- bit 0 butterflies, 1 CFAR cells, 2 scan,
-//                     3 FFT exchanges, 4 magnitude
+//                     3 FFT exchanges, 4 magnitude; quad kernel also: 5 loads from 64 L2-resident frames
+//                     instead of the batch, 6 no word stores (5 + 6 = the kernel's compute alone)
 //   -DRSP_STAMP       s_memtime at the phase boundaries of a few workgroups, printed by one wave each
 //                     (tools/stamp.sh): where a workgroup's lifetime goes while the chip is loaded
 //   -DRSP_COUNT_PATH  ONE path of the run-time mode switches (CA, no peak grouping, JPL, no detection
@@ -18,7 +19,16 @@
 
 namespace rsp {
 
-struct SideHooks {
+// what every hook policy offers by default
+struct PlainHooks {
+  static constexpr bool kSerialQuads = false;  // quad tail, F32: schedule the four quads of a thread one after the other
+  static __device__ __forceinline__ void barrier() { __syncthreads(); }       // the barrier inside an FFT exchange
+  __device__ __forceinline__ void before_stores() {}                            // quad tail: in front of the word stores
+  template <int P> __device__ __forceinline__ void before_exchange() {}         // in front of exchange P's LDS writes
+  template <int P> __device__ __forceinline__ void after_exchange_barrier() {}  // behind the barrier of exchange P
+};
+
+struct SideHooks : PlainHooks {
 #ifdef RSP_ABLATE
   int mask = 0;
   __device__ __forceinline__ void init(const ChainRegs& rg) { mask = rg.sub_window; }
@@ -46,7 +56,7 @@ struct SideHooks {
 };
 
 // the stand-in of kernels that take no hooks (2-D chain)
-struct NoHooks {
+struct NoHooks : PlainHooks {
   __device__ __forceinline__ bool off(int) const { return false; }
   __device__ __forceinline__ void stamp(int) {}
 };

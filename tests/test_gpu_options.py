@@ -132,3 +132,34 @@ def test_f32_window(gpu, window, n):
     thr, peak, margin, mag = O.chain_f32(x, oracle_fcfg(params, rt), want_mag=True)
     compare_f32(got, thr, peak, margin, mag)
     assert not np.array_equal(got, run(make_params(n, dtype=R.F32), rt, x))
+
+
+
+def test_host_entry_pipeline_chunks_and_pinned_buffers(gpu):
+    """rsp_chain_process moves the batch as chunks on three streams (H2D || kernels || D2H); pageable memory goes
+    through the pinned staging ring, rsp_host_alloc'd memory over the link in place.  Every route gives the words of
+    the one-launch device call -- with chunks smaller than the batch, a ragged last chunk, more chunks than staging
+    slots -- and the detection call (chunked kernels + ONE compaction) the dense peaks."""
+    n, frames = 1024, 1000
+    params = make_params(n)
+    rt = rt_for(n, R.CACFARType, 4)
+    beats = np.concatenate([tone_beats(8, n, 5), random_beats(frames - 8, n, 9)])
+    ref = O.chain_fixed(beats, oracle_cfg(params, rt)).reshape(frames, n)
+    with R.FftMagCfarChainVanilla(params) as dut:
+        dut.configure(rt)
+        assert np.array_equal(dut.stream(beats), ref)                       # one chunk (4 MB < 16 MiB)
+        dut.set_option(dut.HOST_CHUNK_BYTES, 300 * 1024)                    # 64-frame chunks: 16 of them, ragged last
+        assert np.array_equal(dut.stream(beats), ref)
+        hin, hout = R.HostBuffer((frames, n), np.uint32), R.HostBuffer(frames * n, np.uint32)
+        hin.array[...] = beats
+        hout.array[...] = 0
+        got = dut.stream(hin.array, out=hout.array)                         # pinned both ways
+        assert np.array_equal(got, ref) and np.array_equal(hout.array.reshape(frames, n), ref)
+        out2 = np.zeros(frames * n, np.uint32)
+        assert np.array_equal(dut.stream(hin.array, out=out2), ref)         # pinned in, pageable out
+        det, found = dut.detections(beats)
+        fr, bn = np.nonzero(ref & 1)
+        assert found == fr.size and np.array_equal(det["frame"], fr) and np.array_equal(det["bin"], bn)
+        assert np.array_equal(det["word"], ref[fr, bn])
+        with pytest.raises(ValueError):
+            dut.stream(beats, out=np.zeros(5, np.uint32))

@@ -22,6 +22,8 @@ dut = R.FftMagCfarChainVanilla(params)
 dut.configure(rt)
 if os.environ.get("RSP_PROF_GENERIC_TAIL"):   # A/B: the per-cell tail instead of the quad tail
     dut.set_option(dut.FORCE_GENERIC_TAIL, 1)
+if os.environ.get("RSP_PROF_EXPERIMENT"):     # A/B: the experimental kernel of a side library (tools/build_experiment.sh)
+    dut.set_option(dut.EXPERIMENT, 1)
 sets = 4
 if dtype == R.F32:
     x = R.stimulus.chirp_frames(64, n, seed=1234)
