@@ -15,18 +15,25 @@ two CPU baselines timed on this box's host cores: the float64 oracle on all core
 and the bit-accurate fixed-point model of the reference's own configuration on ONE thread
 ("cpu_baseline_fixed", SURVEY 8d-i: the closest analogue of the Chisel simulation, which cannot run here).
 
-N > 1 (BASELINE.json configs[4] = "cfg5"): 64 Rx channels of 8192 x 1024 range-Doppler maps sharded
-over the N ranks (contiguous channels per rank, rsp_chains_amd.dist.shard_range), 2-D FFT + JPL
-magnitude + 2-D CA-CFAR per channel, per-rank compaction, and ONE RCCL all-gather of the packed
-detection lists per step on a side stream.  Total work is fixed (64 channels): "scaling": "strong".
-No data-path collective; the gather's cost is reported separately.
+N > 1 (BASELINE.json configs[4] = "cfg5" at N = 8): 8 Rx channels of 8192 x 1024 range-Doppler maps PER GPU
+(8 N channels in all, contiguous channels per rank, rsp_chains_amd.dist.shard_range; N = 8 is the 64-Rx
+configuration), 2-D FFT + JPL magnitude + 2-D CA-CFAR per channel, the list appended by the CFAR kernel, and ONE
+RCCL all-gather per step of the packed detection lists -- sized to the lists, not to their capacity -- on a side
+stream.  Per-GPU work is fixed: "scaling": "weak"; the N = 1 line carries the same 8-Rx share as
+`scaling_baseline` (machine-readable: value(N) / (N x scaling_baseline.value) is the efficiency of THIS workload;
+the N = 1 headline is a different, lighter configuration).  No data-path collective; the gather's cost is
+reported separately.
 
-Timing: W warm-up steps, then 5 blocks of K steps, each block bracketed by barrier +
-synchronize on both sides and reduced with MAX over ranks; the line reports the MEDIAN block
-(`blocks_ms` lists all five).  `roofline` is for the dominant kernel: algorithmic bytes
-/ its mean launch duration measured with one HIP event pair per launch on the stream the kernel
-runs on (rsp_chain_profile_*) over a repeat of the same blocks -- the event records perturb the
-stream by ~1 us per step, so they are kept out of the blocks `value` comes from.
+Timing: W warm-up steps, then a PRE-HEAT of back-to-back steps until the step time is stationary (>= 150 ms; the
+chip's clock moves under load and a 1-ms block measures a transient), then 5 blocks.  A block = R passes over the K
+steps, R chosen so that a block is >= 50 ms of GPU time whatever K is; every block is bracketed by barrier +
+synchronize on both sides and reduced with MAX over ranks.  `value` = the MEDIAN block (sustained), `best_block`
+the fastest; `blocks_ms` lists all five and `sclk_mhz` the shader clock the driver reported before / after each
+(sysfs pp_dpm_sclk), so that a slow block is attributable.  `roofline` is for the dominant kernel: algorithmic bytes
+ / its mean launch duration measured with one HIP event pair per launch on the stream the kernel runs on
+(rsp_chain_profile_*) over a repeat of one block -- the event records perturb the stream by ~1 us per step, so
+they are kept out of the blocks `value` comes from; an event pair brackets dispatch + kernel, ~1-2 us more than the
+kernel's own begin / end timestamps that rocprofv3 reports (profiles/).
 Prints ONE JSON line (rank 0).
 """
 from __future__ import annotations
@@ -45,7 +52,46 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 N_SETS = 4             # rotate 4 x (134 MB in + 67 MB out) = 805 MB > 2 x the 256 MiB Infinity Cache
 N_BLOCKS = 5
+BLOCK_MIN_S = 0.050    # a timed block is at least this much GPU time (a pass over --steps is repeated inside it)
+PREHEAT_MIN_S, PREHEAT_MAX_S = 0.150, 1.0
 METRIC = "range-Doppler cells/sec (FFT+CFAR)"
+
+
+class SclkReader:
+    """Current shader clock (MHz) from the amdgpu driver's sysfs table of the device this rank runs on.  None when the
+    table is not readable on this box (the line then says so; the clock is a label, never an input)."""
+
+    def __init__(self, torch, dev):
+        import glob
+        self.path = None
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+        except Exception:
+            pass
+        cands = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        for c in cands:
+            try:
+                real = os.path.realpath(os.path.dirname(c))
+            except OSError:
+                continue
+            if want and want in real:
+                self.path = c
+                break
+        if self.path is None and len(cands) == 1:
+            self.path = cands[0]
+
+    def __call__(self):
+        if not self.path:
+            return None
+        try:
+            for line in open(self.path):
+                if line.rstrip().endswith("*"):
+                    return int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+        except Exception:
+            return None
+        return None
 
 
 def median(v):
@@ -63,6 +109,9 @@ class Fence:
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
+    def sync_only(self):
+        self.torch.cuda.synchronize()
+
     def max_over_ranks(self, seconds):
         if not self.use_dist:
             return seconds
@@ -71,26 +120,54 @@ class Fence:
         return float(t.item())
 
 
-def timed_blocks(step, steps, warmup, fence, first=0):
-    """warm-up, then N_BLOCKS blocks of `steps` steps; returns per-block seconds (max over ranks)."""
+def timed_blocks(step, steps, warmup, fence, first=0, sclk=None):
+    """warm-up, pre-heat to a stationary step time, then N_BLOCKS blocks of `reps` passes over `steps` steps.
+    Returns a dict: per-block seconds PER STEP (max over ranks), reps, the clock readings, the next step index."""
     i = first
     for _ in range(warmup):
         step(i)
         i += 1
-    out = []
+    # pre-heat: windows of >= 25 ms until two consecutive ones agree within 3 % (and >= 150 ms in all).  Every decision
+    # is taken on MAX-over-ranks times, so that all ranks run the same number of steps (a step may hold a collective).
+    fence()
+    total, prev, per_step = 0.0, None, None
+    n_win = max(steps, 8)
+    while True:
+        t0 = time.perf_counter()
+        for _ in range(n_win):
+            step(i)
+            i += 1
+        fence.sync_only()
+        dt = fence.max_over_ranks(time.perf_counter() - t0)
+        total += dt
+        per_step = dt / n_win
+        if dt < 0.025 and total < PREHEAT_MAX_S:
+            n_win = int(n_win * max(2.0, 0.03 / max(dt, 1e-6))) + 1
+            continue
+        stationary = prev is not None and abs(per_step - prev) <= 0.03 * prev
+        if (total >= PREHEAT_MIN_S and stationary) or total >= PREHEAT_MAX_S:
+            break
+        prev = per_step
+    preheat_s = total
+    reps = max(1, int(np.ceil(BLOCK_MIN_S / max(per_step * steps, 1e-9))))
+    out, clocks = [], []
     for _ in range(N_BLOCKS):
         fence()
+        c0 = sclk() if sclk else None
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(reps * steps):
             step(i)
             i += 1
         fence()
-        out.append(fence.max_over_ranks(time.perf_counter() - t0))
-    return out, i
+        dt = time.perf_counter() - t0
+        clocks.append([c0, sclk() if sclk else None])
+        out.append(fence.max_over_ranks(dt) / (reps * steps))
+    return {"per_step_s": out, "reps": reps, "sclk_mhz": clocks, "next": i, "preheat_s": preheat_s}
 
 
 def kernel_ms(dut, step, steps, first, fence):
     """mean duration of the chain kernel(s) per step: HIP event pair per launch, same step sequence."""
+    steps = min(steps, 1000)  # one event pair per launch: bounded
     fence()
     dut.profile_enable(True)
     for i in range(steps):
@@ -114,11 +191,13 @@ def roofline(kernel, kms, algorithmic_bytes, traffic=None, traffic_source=None):
 def static_traffic(key):
     """HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs, gfx950 FETCH_SIZE x2
     correction: profiles/README.md).  Static: it describes the kernel as profiled for this round, not this run."""
-    for name in ("traffic_r02.json", "traffic_r01.json"):
+    for name in ("traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             try:
-                v = json.load(open(path)).get(key)
+                v = json.load(open(path))
+                for k in key.split("/"):
+                    v = v.get(k) if isinstance(v, dict) else None
                 if v:
                     return v, f"profiles/{name} (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel)"
             except Exception:
@@ -236,22 +315,82 @@ def make_cfg4(R, torch, dev, local_rank, rank, nr=8192, frames=2048):
                 name=f"cfg4: OS-CFAR (32-cell window, k = 24, G = 4) on {nr}-pt spectra, {frames}-chirp batch, fp32, dense words")
 
 
-def run_extra(w, torch, steps, warmup):
-    """one extra configuration on this GPU: median block + kernel time, freed afterwards"""
-    stream = torch.cuda.current_stream()
-    w["dut"].set_stream(stream.cuda_stream)
-    fence = Fence(torch, None, False, None)
-    blocks, nxt = timed_blocks(w["step"], steps, warmup, fence)
-    kms, _ = kernel_ms(w["dut"], w["step"], steps, nxt, fence)
-    sec = median(blocks)
+def make_fixed(R, torch, dev, local_rank, n, frames, ref):
+    """FIXED16 1-D chain = the reference's own arithmetic (FixedPoint(16.W, 12.BP), FftMagCfarChain.scala:79-81):
+    the tester's stimulus (3 tones + noise, RspChainTesterUtils.scala:56-67), CA-CFAR, G = 4; 8 B per cell"""
+    params = R.FftMagCfarVanillaParameters(
+        fftParams=R.FFTParams.fixed(numPoints=n), magParams=R.MAGParams.fixed(),
+        cfarParams=R.CFARParams(fftSize=n), dtype=R.FIXED16, device=local_rank)
+    rt = R.RunTimeRspChainParams(fftSize=n, CFARMode="Cell Averaging", refWindowSize=ref, guardWindowSize=4,
+                                 divSum=ref.bit_length() - 1, thresholdScaler=3.5)
+    dut = R.FftMagCfarChainVanilla(params)
+    dut.configure(rt)
+    uniq = 64
+    beats = np.stack([R.stimulus.formAXI4StreamComplexData(
+        R.stimulus.getComplexTones(n, 0.125, 0.25, 0.5, shiftRangeFactor=12, seed=1234 + f)) for f in range(uniq)])
+    host = np.tile(beats, (frames // uniq, 1)).astype(np.uint32)
+    ins = [torch.from_numpy(host.view(np.int32)).to(dev) for _ in range(N_SETS)]
+    outs = [torch.empty(frames, n, dtype=torch.int32, device=dev) for _ in range(N_SETS)]
+
+    def step(i):
+        s = i % N_SETS
+        dut.process_device(ins[s].data_ptr(), frames, outs[s].data_ptr())
+
+    return dict(dut=dut, step=step, cells=n * frames, bytes=8.0 * n * frames, kernel=f"chain1d_quad_kernel<{n.bit_length() - 1},fixed16>",
+                name=f"FIXED16 (the reference's data type): {n}-pt FFT + JPL + CA-CFAR (R={ref},G=4), {frames}-frame batch, dense words")
+
+
+def summarise(w, steps, tb, kms, traffic=None, traffic_src=None):
+    per = tb["per_step_s"]
+    sec = median(per)
     det = None
     if w.get("lists") is not None:
         found, stored = (int(v) for v in w["lists"][0][0, :2].tolist())
         det = {"found": found, "stored": stored}
-    return {"workload": w["name"], "cells_per_step": w["cells"], "steps": steps, "ms_per_step": sec / steps * 1e3,
-            "detections_per_step": det,
-            "value": w["cells"] * steps / sec, "unit": "cells/s", "blocks_ms": [b / steps * 1e3 for b in blocks],
-            "roofline": roofline(w["kernel"], kms, w["bytes"])}
+    return {"workload": w["name"], "cells_per_step": w["cells"], "steps": steps, "ms_per_step": sec * 1e3,
+            "detections_per_step": det, "value": w["cells"] / sec, "best_block": w["cells"] / min(per), "unit": "cells/s",
+            "blocks_ms": [b * 1e3 for b in per], "block_reps": tb["reps"], "sclk_mhz": tb["sclk_mhz"],
+            "roofline": roofline(w["kernel"], kms, w["bytes"], traffic, traffic_src)}
+
+
+def run_extra(w, torch, steps, warmup, sclk, traffic_key=None):
+    """one extra configuration on this GPU: sustained median block + kernel time, freed afterwards"""
+    stream = torch.cuda.current_stream()
+    w["dut"].set_stream(stream.cuda_stream)
+    fence = Fence(torch, None, False, None)
+    tb = timed_blocks(w["step"], steps, warmup, fence, sclk=sclk)
+    kms, _ = kernel_ms(w["dut"], w["step"], steps * tb["reps"], tb["next"], fence)
+    traffic, src = static_traffic(traffic_key) if traffic_key else (None, None)
+    return summarise(w, steps, tb, kms, traffic, src)
+
+
+def host_entry(R, local_rank, n=4096, frames=4096):
+    """The host-buffer entry rsp_chain_process -- what the reference-side binding calls (FftMagCfarChainTester.scala:137,
+    145-151 -> JNI) -- on the cfg-2 batch: PCIe-inclusive, never `value`.  Pageable NumPy arrays (staged through the
+    pinned ring) and buffers from rsp_host_alloc (DMA in place); both the chunked H2D || kernel || D2H pipeline."""
+    params = R.FftMagCfarVanillaParameters(fftParams=R.FFTParams.fixed(numPoints=n), magParams=R.MAGParams.fixed(),
+                                           cfarParams=R.CFARParams(fftSize=n), dtype=R.F32, device=local_rank)
+    out = {}
+    with R.FftMagCfarChainVanilla(params) as dut:
+        dut.configure(R.RunTimeRspChainParams(fftSize=n, CFARMode="Cell Averaging", refWindowSize=32, guardWindowSize=4,
+                                              divSum=5, thresholdScaler=3.5))
+        x = np.tile(R.stimulus.chirp_frames(64, n, seed=1), (frames // 64, 1))
+        hin, hout = R.HostBuffer((frames, n), np.complex64, local_rank), R.HostBuffer(frames * n, np.uint32, local_rank)
+        hin.array[...] = x
+        pageable_out = np.zeros(frames * n, np.uint32)
+        for tag, a, o in (("pageable", x, pageable_out), ("pinned", hin.array, hout.array)):
+            dut.stream(a, out=o)
+            t = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                dut.stream(a, out=o)
+                t.append(time.perf_counter() - t0)
+            out[tag] = {"ms_per_batch": median(t) * 1e3, "cells_per_s": n * frames / median(t)}
+        out["results_identical"] = bool(np.array_equal(pageable_out, hout.array))
+        hin.free()
+        hout.free()
+    out["entry"] = "rsp_chain_process, cfg-2 batch (134 MB in + 67 MB out over PCIe), chunked H2D || kernel || D2H on three streams"
+    return out
 
 
 # ---------------------------------------------------------------------------------------- main
@@ -296,11 +435,12 @@ def main():
     torch.cuda.set_stream(main_stream)
     assert main_stream.cuda_stream != 0
     fence = Fence(torch, dist, use_dist, dev)
+    sclk = SclkReader(torch, dev)
     workload = args.workload or ("cfg2" if world == 1 and not use_dist else "cfg5")
     if workload == "cfg5":
-        line = run_cfg5(args, torch, dist, R, rank, local_rank, world, dev, use_dist, main_stream, fence)
+        line = run_cfg5(args, torch, dist, R, rank, local_rank, world, dev, use_dist, main_stream, fence, sclk)
     else:
-        line = run_cfg2(args, torch, dist, R, rank, local_rank, world, dev, use_dist, main_stream, fence)
+        line = run_cfg2(args, torch, dist, R, rank, local_rank, world, dev, use_dist, main_stream, fence, sclk)
     if rank == 0:
         json_out.write(json.dumps(line) + "\n")
         json_out.flush()
@@ -308,26 +448,33 @@ def main():
         dist.destroy_process_group()
 
 
-def run_cfg2(args, torch, dist, R, rank, local_rank, world, dev, use_dist, main_stream, fence):
+def run_cfg2(args, torch, dist, R, rank, local_rank, world, dev, use_dist, main_stream, fence, sclk):
     w = make_cfg2(R, torch, dev, local_rank, rank)
     dut, step = w["dut"], w["step"]
     dut.set_stream(main_stream.cuda_stream)
-    blocks, nxt = timed_blocks(step, args.steps, args.warmup, fence)
-    kms, launches = kernel_ms(dut, step, args.steps, nxt, fence)
-    sec = median(blocks)
+    tb = timed_blocks(step, args.steps, args.warmup, fence, sclk=sclk)
+    nxt = tb["next"]
+    kms, launches = kernel_ms(dut, step, args.steps * tb["reps"], nxt, fence)
+    per = tb["per_step_s"]
+    sec = median(per)
     found, stored = (int(v) for v in w["lists"][(nxt - 1) % N_SETS][0, :2].tolist())
     line = None
     if rank == 0:
         traffic, src = static_traffic("chain1d_hbm_bytes_per_launch")
         line = {
-            "metric": METRIC, "value": w["cells"] * world * args.steps / sec, "unit": "cells/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec / args.steps * 1e3,
+            "metric": METRIC, "value": w["cells"] * world / sec, "unit": "cells/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "blocks": N_BLOCKS, "blocks_ms": [b / args.steps * 1e3 for b in blocks], "timing": "median of 5 blocks of `steps` steps",
+            "best_block": w["cells"] * world / min(per),
+            "blocks": N_BLOCKS, "blocks_ms": [b * 1e3 for b in per], "block_reps": tb["reps"], "sclk_mhz": tb["sclk_mhz"],
+            "preheat_ms": tb["preheat_s"] * 1e3,
+            "timing": (f"pre-heated to a stationary step time, then {N_BLOCKS} blocks of block_reps x steps steps (>= 50 ms each); "
+                       "value = median block (sustained), best_block = fastest; sclk_mhz = driver-reported shader clock before / after each block"),
             "config": {"workload": w["name"], "cells_per_step_per_gpu": w["cells"], "buffer_sets": N_SETS,
                        "detections_last_step": {"found": found, "stored": stored}},
             "roofline": roofline(w["kernel"], kms, w["bytes"], traffic, src),
         }
+        line["roofline"]["kernel_ms_launches"] = launches
     if world == 1 and not use_dist and not args.no_extra:
         x0 = w["ins"][0]
         host_sample = x0[:2048].cpu().numpy().view(np.complex64).reshape(2048, w["n"])
@@ -335,37 +482,48 @@ def run_cfg2(args, torch, dist, R, rank, local_rank, world, dev, use_dist, main_
         torch.cuda.empty_cache()
         extra = {}
         steps_x = max(8, args.steps // 3)
-        for tag, make in (("cfg3", lambda: make_rd(R, torch, dev, local_rank, rank, 4096, 512, 8, "cfg3")),
-                          ("cfg4", lambda: make_cfg4(R, torch, dev, local_rank, rank)),
-                          ("cfg5_share", lambda: make_rd(R, torch, dev, local_rank, rank, 8192, 1024, 8,
-                                                        "cfg5 share (8 of 64 Rx)", sets=2))):
+        jobs = (("cfg3", lambda: make_rd(R, torch, dev, local_rank, rank, 4096, 512, 8, "cfg3"), "cfg3_2d_chain/hbm_bytes_all_three_kernels"),
+                ("cfg4", lambda: make_cfg4(R, torch, dev, local_rank, rank), "cfg4_gos/hbm_bytes_per_launch"),
+                ("cfg5_share", lambda: make_rd(R, torch, dev, local_rank, rank, 8192, 1024, 8, "cfg5 share (8 of 64 Rx)", sets=2),
+                 "cfg5_share_2d_chain/hbm_bytes_all_three_kernels"),
+                ("fixed16_cfg1", lambda: make_fixed(R, torch, dev, local_rank, 1024, 16384, 16), "fixed16_cfg1/hbm_bytes_per_launch"),
+                ("fixed16_4096", lambda: make_fixed(R, torch, dev, local_rank, 4096, 4096, 32), "fixed16_4096/hbm_bytes_per_launch"))
+        for tag, make, tkey in jobs:
             wx = make()
-            extra[tag] = run_extra(wx, torch, steps_x if tag != "cfg5_share" else max(4, steps_x // 2), 3)
+            extra[tag] = run_extra(wx, torch, steps_x if tag != "cfg5_share" else max(4, steps_x // 2), 3, sclk, tkey)
             del wx
             torch.cuda.empty_cache()
+        extra["host_entry"] = host_entry(R, local_rank)
         line["extra"] = extra
+        # the same per-GPU work the N > 1 lines run (8 Rx of 8192 x 1024 per GPU): the 1-GPU point of THAT scaling curve
+        line["scaling_baseline"] = {"workload": extra["cfg5_share"]["workload"], "value": extra["cfg5_share"]["value"],
+                                    "unit": "cells/s", "n_gpus": 1,
+                                    "note": "bench.py --gpus N (N > 1) runs this workload on every GPU (weak scaling); the headline `value` is configs[1]"}
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(host_sample, 4096, 4096)
             line["cpu_baseline_fixed"] = cpu_baseline_fixed()
     return line
 
 
-def run_cfg5(args, torch, dist, R, rank, local_rank, world, dev, use_dist, main_stream, fence):
-    """BASELINE.json configs[4]: 64 Rx x 8192 x 1024, channels sharded over the ranks, RCCL gather of the lists."""
-    from rsp_chains_amd.dist import gather_packed, shard_range
-    total_ch, nr, nd = 64, 8192, 1024
+def run_cfg5(args, torch, dist, R, rank, local_rank, world, dev, use_dist, main_stream, fence, sclk):
+    """BASELINE.json configs[4] at N = 8: 8 Rx x 8192 x 1024 per GPU (64 Rx on eight), RCCL gather of the lists."""
+    from rsp_chains_amd.dist import PackedGatherer, shard_range
+    per_gpu, nr, nd = 8, 8192, 1024
+    total_ch = per_gpu * world
     lo, hi = shard_range(total_ch, rank, world)
     n_ch = hi - lo
-    w = make_rd(R, torch, dev, local_rank, rank, nr, nd, n_ch, f"cfg5: {total_ch} Rx sharded {n_ch}/GPU", sets=2)
+    w = make_rd(R, torch, dev, local_rank, rank, nr, nd, n_ch, f"cfg5: {total_ch} Rx, {n_ch} per GPU", sets=2)
     dut, sets, cap = w["dut"], w["sets"], w["cap"]
     dut.set_stream(main_stream.cuda_stream)
     lists = w["lists"]
     gather = use_dist
     if gather:
         comm = torch.cuda.Stream(device=dev)
+        pg = PackedGatherer(cap)
         g_lists = [torch.empty(world * (cap + 1), 4, dtype=torch.int32, device=dev) for _ in range(sets)]
         ready = [torch.cuda.Event() for _ in range(sets)]
         gathered = [torch.cuda.Event() for _ in range(sets)]
+        views = [None] * sets
     state = {"gather": gather}
 
     def step(i):
@@ -377,42 +535,58 @@ def run_cfg5(args, torch, dist, R, rank, local_rank, world, dev, use_dist, main_
             ready[s].record(main_stream)
             with torch.cuda.stream(comm):
                 comm.wait_event(ready[s])
-                gather_packed(lists[s], out=g_lists[s])
+                views[s] = pg.gather(lists[s], out=g_lists[s])
                 gathered[s].record(comm)
 
-    blocks, nxt = timed_blocks(step, args.steps, args.warmup, fence)
-    sec = median(blocks)
+    if gather:  # size the payload to the lists (off the clock): two steps, read their headers, grow if needed
+        for i in range(sets):
+            step(i)
+        fence()
+        for v in views:
+            pg.settle(v)
+    tb = timed_blocks(step, args.steps, args.warmup, fence, sclk=sclk)
+    per = tb["per_step_s"]
+    sec = median(per)
+    complete = True
+    if gather:  # every list of the timed steps fitted the rows that travelled?
+        fence()
+        complete = all(pg.settle(v) for v in views if v is not None)
     # the same steps without the collective: what the gather costs end to end
     state["gather"] = False
-    blocks_ng, nxt = timed_blocks(step, args.steps, 1, fence, first=nxt)
-    sec_ng = median(blocks_ng)
-    kms, _ = kernel_ms(dut, w["step"], args.steps, nxt, fence)
+    tb_ng = timed_blocks(step, args.steps, 1, fence, first=tb["next"])
+    sec_ng = median(tb_ng["per_step_s"])
+    kms, _ = kernel_ms(dut, w["step"], args.steps * tb["reps"], tb_ng["next"], fence)
     gather_ms = None
     if gather:  # the collective alone, back to back on its stream
         fence()
         t0 = time.perf_counter()
         for k in range(20):
-            gather_packed(lists[k % sets], out=g_lists[k % sets])
+            pg.gather(lists[k % sets], out=g_lists[k % sets])
         fence()
         gather_ms = fence.max_over_ranks(time.perf_counter() - t0) / 20 * 1e3
     if rank != 0:
         return None
     cells_total = total_ch * nd * nr
+    traffic, src = static_traffic("cfg5_share_2d_chain/hbm_bytes_all_three_kernels")
     return {
-        "metric": METRIC, "value": cells_total * args.steps / sec, "unit": "cells/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "blocks": N_BLOCKS, "blocks_ms": [b / args.steps * 1e3 for b in blocks], "timing": "median of 5 blocks of `steps` steps",
+        "metric": METRIC, "value": cells_total / sec, "unit": "cells/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "best_block": cells_total / min(per),
+        "blocks": N_BLOCKS, "blocks_ms": [b * 1e3 for b in per], "block_reps": tb["reps"], "sclk_mhz": tb["sclk_mhz"],
+        "timing": (f"pre-heated, then {N_BLOCKS} blocks of block_reps x steps steps (>= 50 ms each); value = median block, "
+                   "MAX over ranks per block"),
         "config": {"workload": w["name"] + "; RCCL all-gather of the packed lists, one per step, side stream",
                    "cells_per_step_total": cells_total, "channels_per_gpu": n_ch, "buffer_sets": sets,
                    "sharding": "contiguous channels per rank (dist.shard_range); no data-path collective"},
-        "gather": {"ms_per_collective_alone": gather_ms, "ms_per_step_without_gather": sec_ng / args.steps * 1e3,
-                   "bytes_per_rank": (cap + 1) * 16},
-        "scaling_note": ("N > 1 lines run BASELINE.json configs[4] (64 Rx, fixed total work); the N = 1 line's headline is configs[1] "
-                         "(a different, lighter workload per cell), so scaling efficiency is value(N) / (N/8 x 8 x the N = 1 line's "
-                         "extra.cfg5_share.value), i.e. against the same 8-Rx-per-GPU share measured on one GPU"),
-        "per_gpu_value": cells_total * args.steps / sec / world,
-        "roofline": roofline(w["kernel"], kms, 28.0 * n_ch * nd * nr),
+        "gather": {"ms_per_collective_alone": gather_ms, "ms_per_step_without_gather": sec_ng * 1e3,
+                   "rows_per_rank": pg.rows if gather else None, "bytes_per_rank": pg.rows * 16 if gather else None,
+                   "capacity_rows": cap + 1, "every_timed_list_complete": complete},
+        "scaling_note": ("weak scaling: 8 Rx of 8192 x 1024 per GPU at every N (N = 8 is BASELINE.json configs[4]); the 1-GPU point of this "
+                         "curve is the N = 1 line's `scaling_baseline` (= extra.cfg5_share), NOT its headline `value` (configs[1], a lighter "
+                         "workload per cell)"),
+        "per_gpu_value": cells_total / sec / world,
+        "roofline": roofline(w["kernel"], kms, 28.0 * n_ch * nd * nr, traffic, src),
     }
 
 

@@ -379,7 +379,7 @@ class FftMagCfarChainVanilla:
         uint32: {peaks found, entries stored}."""
         _check(self._lib.rsp_chain_process_detect_device(self._h, C.c_void_p(d_in), n_frames,
                                                          C.c_void_p(d_out) if d_out else None,
-                                                         C.c_void_p(d_list), cap, C.c_void_p(d_count)))
+                                                         C.c_void_p(d_list) if d_list else None, cap, C.c_void_p(d_count)))
 
     def detections_device(self, d_words: int, n_frames: int, d_list: int, cap: int, d_count: int):
         _check(self._lib.rsp_chain_detections_device(self._h, C.c_void_p(d_words), n_frames,

@@ -858,7 +858,11 @@ static hipError_t launch_rd2d_chunk(const Rd2dLaunch& a, uint32_t ch0, uint32_t 
   const float* wr = reinterpret_cast<const float*>(a.regs.window);
   const float* wd = reinterpret_cast<const float*>(a.win_doppler);
   const uint32_t rows = n_ch * nd, tile = rd_tile(a.log2nr);
-  uint32_t* zero_count = (a.det_list && ch0 == 0) ? a.det_count : nullptr;  // first chunk of the batch
+  uint32_t* zero_count = (a.det_count && ch0 == 0) ? a.det_count : nullptr;  // first chunk of the batch
+  // count-only call (cap = 0, no list buffer): the kernels count their peaks when handed ANY non-null list pointer and
+  // never store through it (every store is behind `slot < cap`)
+  rsp_detection* det_list = a.det_count ? (a.det_list ? a.det_list : reinterpret_cast<rsp_detection*>(a.det_count)) : nullptr;
+  const uint32_t det_cap = a.det_list ? a.det_cap : 0u;
   switch (a.log2nr) {
     case 8: e = launch_range_m<8>(in, x1, rows, a.log2nd, tile, twr, wr, zero_count, a.stream, a.device); break;
     case 9: e = launch_range_m<9>(in, x1, rows, a.log2nd, tile, twr, wr, zero_count, a.stream, a.device); break;
@@ -895,7 +899,7 @@ static hipError_t launch_rd2d_chunk(const Rd2dLaunch& a, uint32_t ch0, uint32_t 
     const dim3 grid(n_ch * strips * (nd / SEG / 4));
 #define RSP_WALK(MODE)                                                                                              \
   hipLaunchKernelGGL((cfar2d_walk_kernel<8, 2, 8, 2, SEG, MODE>), grid, dim3(256), 0, a.stream, a.scratch_mag, out, \
-                     nd, nr, strips, a.regs.edge, kA, kB, a.det_list, a.det_cap, a.det_count, ch0, tile, a.regs, a.log2nr)
+                     nd, nr, strips, a.regs.edge, kA, kB, det_list, det_cap, a.det_count, ch0, tile, a.regs, a.log2nr)
     if (a.regs.cfar_mode == 0) RSP_WALK(0);
     else if (a.regs.cfar_mode == 1) RSP_WALK(1);
     else RSP_WALK(2);
@@ -907,7 +911,7 @@ static hipError_t launch_rd2d_chunk(const Rd2dLaunch& a, uint32_t ch0, uint32_t 
   e = grant_lds(k, lds, a.device, granted);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3(n_ch * (nr / kTR) * (nd / kTD)), dim3(256), lds, a.stream, a.scratch_mag, out,
-                     nd, nr, a.regs.R, a.regs.G, a.ref_d, a.guard_d, a.regs.edge, kA, kB, a.det_list, a.det_cap,
+                     nd, nr, a.regs.R, a.regs.G, a.ref_d, a.guard_d, a.regs.edge, kA, kB, det_list, det_cap,
                      a.det_count, ch0, a.regs.cfar_mode, tile, a.regs, a.log2nr);
   return hipGetLastError();
 }
@@ -950,7 +954,11 @@ static hipError_t launch_rd2d_chunk_fx(const Rd2dLaunch& a, uint32_t ch0, uint32
   const uint32_t* twr = reinterpret_cast<const uint32_t*>(a.tw_range);
   const uint32_t* twd = reinterpret_cast<const uint32_t*>(a.tw_doppler);
   const uint32_t rows = n_ch * nd, tile = rd_tile(a.log2nr);
-  uint32_t* zero_count = (a.det_list && ch0 == 0) ? a.det_count : nullptr;
+  uint32_t* zero_count = (a.det_count && ch0 == 0) ? a.det_count : nullptr;
+  // count-only call (cap = 0, no list buffer): the kernels count their peaks when handed ANY non-null list pointer and
+  // never store through it (every store is behind `slot < cap`)
+  rsp_detection* det_list = a.det_count ? (a.det_list ? a.det_list : reinterpret_cast<rsp_detection*>(a.det_count)) : nullptr;
+  const uint32_t det_cap = a.det_list ? a.det_cap : 0u;
   switch (a.log2nr) {
     case 8: e = launch_range_fx<8>(in, x1, rows, nd, tile, twr, a.regs, zero_count, a.stream, a.device); break;
     case 9: e = launch_range_fx<9>(in, x1, rows, nd, tile, twr, a.regs, zero_count, a.stream, a.device); break;
@@ -982,7 +990,7 @@ static hipError_t launch_rd2d_chunk_fx(const Rd2dLaunch& a, uint32_t ch0, uint32
     const dim3 grid(n_ch * strips * (nd / SEG / 4));
 #define RSP_WALK(MODE)                                                                                                   \
   hipLaunchKernelGGL((cfar2d_walk_kernel<8, 2, 8, 2, SEG, MODE, int32_t>), grid, dim3(256), 0, a.stream, mag, out, nd, nr, \
-                     strips, a.regs.edge, 0.f, 0.f, a.det_list, a.det_cap, a.det_count, ch0, tile, a.regs, a.log2nr)
+                     strips, a.regs.edge, 0.f, 0.f, det_list, det_cap, a.det_count, ch0, tile, a.regs, a.log2nr)
     if (a.regs.cfar_mode == 0) RSP_WALK(0);
     else if (a.regs.cfar_mode == 1) RSP_WALK(1);
     else RSP_WALK(2);
@@ -994,7 +1002,7 @@ static hipError_t launch_rd2d_chunk_fx(const Rd2dLaunch& a, uint32_t ch0, uint32
   e = grant_lds(k, lds, a.device, granted);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3(n_ch * (nr / kTR) * (nd / kTD)), dim3(256), lds, a.stream, mag, out,
-                     nd, nr, a.regs.R, a.regs.G, a.ref_d, a.guard_d, a.regs.edge, 0.f, 0.f, a.det_list, a.det_cap,
+                     nd, nr, a.regs.R, a.regs.G, a.ref_d, a.guard_d, a.regs.edge, 0.f, 0.f, det_list, det_cap,
                      a.det_count, ch0, a.regs.cfar_mode, tile, a.regs, a.log2nr);
   return hipGetLastError();
 }
@@ -1003,7 +1011,7 @@ static hipError_t launch_rd2d_chunk_fx(const Rd2dLaunch& a, uint32_t ch0, uint32
 // 4 B/cell) fit the 256 MiB Infinity Cache together with the streams passing by, and every chunk reuses the SAME
 // scratch memory, so the corner turn and the magnitude map are re-read from cache instead of HBM.
 hipError_t launch_rd2d(const Rd2dLaunch& a) {
-  if (a.n_ch == 0) return a.det_list ? hipMemsetAsync(a.det_count, 0, 2 * sizeof(uint32_t), a.stream) : hipSuccess;
+  if (a.n_ch == 0) return a.det_count ? hipMemsetAsync(a.det_count, 0, 2 * sizeof(uint32_t), a.stream) : hipSuccess;
   const uint32_t per = rd2d_chunk_channels(a.log2nr, a.log2nd, a.n_ch, a.chunk_bytes);
   for (uint32_t c0 = 0; c0 < a.n_ch; c0 += per) {
     const uint32_t n = a.n_ch - c0 < per ? a.n_ch - c0 : per;

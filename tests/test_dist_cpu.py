@@ -17,7 +17,8 @@ WORKER = textwrap.dedent("""
     import torch, torch.distributed as dist
     sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
     import rsp_chains_amd as R
-    from rsp_chains_amd.dist import shard_range, gather_detections, gather_packed, unpack_gathered, merge_gathered
+    from rsp_chains_amd.dist import (shard_range, gather_detections, gather_packed, unpack_gathered, merge_gathered,
+                                     gathered_complete, PackedGatherer)
     from oracle import oracle as O
     from helpers import make_params, oracle_cfg, tone_beats
     dist.init_process_group("gloo")
@@ -31,8 +32,18 @@ WORKER = textwrap.dedent("""
     lst = np.zeros((cap, 4), np.int32)
     k = len(fr)
     lst[:k, 0], lst[:k, 1], lst[:k, 3] = fr, bn, words[fr, bn].astype(np.int64).astype(np.int32)
-    lists, counts = gather_detections(torch.from_numpy(lst), torch.tensor([k], dtype=torch.int32), cap)
+    # (found, stored) as the C ABI writes them through d_count; rank 1's list is truncated by one entry
+    st = k if rank == 0 else max(k - 1, 0)
+    lists, counts, founds = gather_detections(torch.from_numpy(lst), torch.tensor([k, st], dtype=torch.int32), cap)
     firsts = [shard_range(frames, r, world)[0] for r in range(world)]
+    mt = merge_gathered(lists, counts, firsts)
+    assert mt.shape[0] == int(counts.sum()) and int(founds.sum()) >= mt.shape[0]
+    try:
+        gather_detections(torch.from_numpy(lst), torch.tensor([k], dtype=torch.int32), cap)
+        raise SystemExit("a one-word count tensor must be refused")
+    except ValueError:
+        pass
+    lists, counts, founds = gather_detections(torch.from_numpy(lst), torch.tensor([k, k], dtype=torch.int32), cap)
     merged = merge_gathered(lists, counts, firsts)
     full = O.chain_fixed(beats, oracle_cfg(params, rt)).reshape(frames, n)
     gfr, gbn = np.nonzero(full & 1)
@@ -51,6 +62,19 @@ WORKER = textwrap.dedent("""
     m2 = merge_gathered(l2, s2, firsts)
     assert int(f2.sum()) == len(want) and m2.shape[0] == int(s2.sum())
     assert (m2[:, 1] >= 0).all() and set(zip(m2[:, 0].tolist(), m2[:, 1].tolist())) <= set(want)
+    # payload sized to the lists: too few rows is detected, the gatherer grows and the repeat is complete
+    packed[0, 1] = k
+    packed[1:] = torch.from_numpy(lst)
+    small = gather_packed(packed, rows=2)
+    assert small.shape == (world, 2, 4) and not gathered_complete(small)
+    pg = PackedGatherer(cap, min_rows=2)
+    v = pg.gather(packed)
+    if not pg.settle(v):
+        v = pg.gather(packed)
+    assert pg.settle(v) and v.shape[1] <= cap + 1 and v.shape[1] >= int(s2.max()) + 1
+    l3, s3, f3 = unpack_gathered(v)
+    m3 = merge_gathered(l3, s3, firsts)
+    assert sorted(zip(m3[:, 0].tolist(), m3[:, 1].tolist())) == want
     dist.barrier(); dist.destroy_process_group()
     print("rank", rank, "ok", len(want))
 """)

@@ -225,6 +225,11 @@ def test_rd2d_detection_list(gpu, tiled):
         found, stored = (int(v) for v in d_cnt2.download(np.uint32, 2))
         assert found == len(want) and stored == 50
         assert set(map(tuple, d_list2.download(np.uint32, 200).reshape(50, 4).tolist())) <= set(want)
+        # count-only call: cap = 0 and NO list buffer (the 1-D chain's count-only form): {found, 0}, nothing stored
+        d_cnt2.upload(np.array([0xdead, 0xbeef], np.uint32))
+        dut.process_detect_device(d_in.ptr, n_ch, d_out2.ptr, 0, 0, d_cnt2.ptr)
+        dut.synchronize()
+        assert [int(v) for v in d_cnt2.download(np.uint32, 2)] == [len(want), 0]
         det, found_h = dut.detections(x)
         assert found_h == len(want)
         assert [(int(a), int(b), int(c), int(w)) for a, b, c, w in zip(det["frame"], det["bin"], det["doppler"], det["word"])] == \

@@ -1,4 +1,5 @@
 #!/bin/bash
-# phase ablation of chain1d (build with -DRSP_ABLATE): bit0 butterflies, bit1 CFAR cells, bit2 scan,
-# bit3 LDS exchange traffic, bit4 magnitude math
-for m in 0 1 2 4 8 16 3 9 25 27 31; do echo -n "mask=$m: "; RSP_ABLATE_MASK=$m RSP_CHAIN_LIB=$PWD/ab_ablate.so python3 tools/prof_chain.py 4096 4096 30 | tail -1; done
+# Phase ablation of the fp32 4096-point quad kernel (side build: tools/build_variant.sh ab_ablate.so -DRSP_ABLATE).
+# Mask bits (csrc/side_build.hpp): 1 butterflies, 2 CFAR cells, 4 scan, 8 FFT exchanges, 16 magnitude,
+# 32 loads from 64 L2-resident frames, 64 no word stores.  96 = the kernel's compute alone; 96 + x = compute without x.
+for m in 0 32 64 96 97 98 100 104 112 99 105 127; do echo -n "mask=$m: "; RSP_ABLATE_MASK=$m RSP_CHAIN_LIB=$PWD/ab_ablate.so python3 tools/prof_chain.py 4096 4096 100 2>/dev/null | tail -1; done

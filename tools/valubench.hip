@@ -1,0 +1,87 @@
+// Issue cost of the VALU / LDS instruction kinds the chain kernels are made of, per wave-instruction, at 1..4 waves
+// per SIMD: s_memtime around an unrolled run of INDEPENDENT instructions.  hipcc --offload-arch=gfx950 -O3
+// tools/valubench.hip -o tools/valubench && tools/valubench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define REP8(x) x x x x x x x x
+#define REP64(x) REP8(REP8(x))
+
+template <int KIND>
+__global__ void __launch_bounds__(1024) bench(unsigned long long* out, float* sink, int iters) {
+  f32x2 a[8], b = {1.0001f, 0.9999f}, c = {0.5f, 0.25f};
+  float s[8];
+  for (int i = 0; i < 8; ++i) { a[i] = f32x2{(float)threadIdx.x + i, (float)i}; s[i] = (float)threadIdx.x * 0.5f + i; }
+  extern __shared__ float lds[];
+  float* lp = lds + threadIdx.x * 4;
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+    if constexpr (KIND == 0) {  // v_pk_fma_f32, 8 independent chains
+      REP8(asm volatile("v_pk_fma_f32 %0, %0, %8, %9\n v_pk_fma_f32 %1, %1, %8, %9\n v_pk_fma_f32 %2, %2, %8, %9\n v_pk_fma_f32 %3, %3, %8, %9\n"
+                        "v_pk_fma_f32 %4, %4, %8, %9\n v_pk_fma_f32 %5, %5, %8, %9\n v_pk_fma_f32 %6, %6, %8, %9\n v_pk_fma_f32 %7, %7, %8, %9"
+                        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b), "v"(c));)
+    } else if constexpr (KIND == 1) {  // v_fma_f32
+      REP8(asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                        "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x), "v"(c.x));)
+    } else if constexpr (KIND == 2) {  // v_pk_add_f32
+      REP8(asm volatile("v_pk_add_f32 %0, %0, %8\n v_pk_add_f32 %1, %1, %8\n v_pk_add_f32 %2, %2, %8\n v_pk_add_f32 %3, %3, %8\n"
+                        "v_pk_add_f32 %4, %4, %8\n v_pk_add_f32 %5, %5, %8\n v_pk_add_f32 %6, %6, %8\n v_pk_add_f32 %7, %7, %8"
+                        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b));)
+    } else if constexpr (KIND == 3) {  // v_add_f32
+      REP8(asm volatile("v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
+                        "v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x));)
+    } else if constexpr (KIND == 4) {  // v_pk_mul_f32 with op_sel (the cmul form)
+      REP8(asm volatile("v_pk_mul_f32 %0, %0, %8 op_sel_hi:[0,1]\n v_pk_mul_f32 %1, %1, %8 op_sel_hi:[0,1]\n v_pk_mul_f32 %2, %2, %8 op_sel_hi:[0,1]\n v_pk_mul_f32 %3, %3, %8 op_sel_hi:[0,1]\n"
+                        "v_pk_mul_f32 %4, %4, %8 op_sel_hi:[0,1]\n v_pk_mul_f32 %5, %5, %8 op_sel_hi:[0,1]\n v_pk_mul_f32 %6, %6, %8 op_sel_hi:[0,1]\n v_pk_mul_f32 %7, %7, %8 op_sel_hi:[0,1]"
+                        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b));)
+    } else if constexpr (KIND == 5) {  // ds_write_b64, lane-contiguous
+      REP8(asm volatile("ds_write_b64 %0, %1\n ds_write_b64 %0, %2 offset:2048\n ds_write_b64 %0, %3 offset:4096\n ds_write_b64 %0, %4 offset:6144\n"
+                        "ds_write_b64 %0, %5 offset:8192\n ds_write_b64 %0, %6 offset:10240\n ds_write_b64 %0, %7 offset:12288\n ds_write_b64 %0, %8 offset:14336\n s_waitcnt lgkmcnt(0)"
+                        :: "v"((unsigned)(threadIdx.x & 255) * 8u), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) : "memory");)
+    } else if constexpr (KIND == 6) {  // ds_read_b64
+      REP8(asm volatile("ds_read_b64 %0, %8\n ds_read_b64 %1, %8 offset:2048\n ds_read_b64 %2, %8 offset:4096\n ds_read_b64 %3, %8 offset:6144\n"
+                        "ds_read_b64 %4, %8 offset:8192\n ds_read_b64 %5, %8 offset:10240\n ds_read_b64 %6, %8 offset:12288\n ds_read_b64 %7, %8 offset:14336\n s_waitcnt lgkmcnt(0)"
+                        : "=v"(a[0]), "=v"(a[1]), "=v"(a[2]), "=v"(a[3]), "=v"(a[4]), "=v"(a[5]), "=v"(a[6]), "=v"(a[7]) : "v"((unsigned)(threadIdx.x & 255) * 8u) : "memory");)
+    } else if constexpr (KIND == 7) {  // interleaved: 4 v_pk_fma per ds_write_b64 (an FFT pass next to its exchange)
+      REP8(asm volatile("ds_write_b64 %8, %0\n v_pk_fma_f32 %0, %0, %9, %10\n v_pk_fma_f32 %1, %1, %9, %10\n v_pk_fma_f32 %2, %2, %9, %10\n v_pk_fma_f32 %3, %3, %9, %10\n"
+                        "ds_write_b64 %8, %4 offset:2048\n v_pk_fma_f32 %4, %4, %9, %10\n v_pk_fma_f32 %5, %5, %9, %10\n v_pk_fma_f32 %6, %6, %9, %10\n v_pk_fma_f32 %7, %7, %9, %10\n s_waitcnt lgkmcnt(0)"
+                        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"((unsigned)(threadIdx.x & 255) * 8u), "v"(b), "v"(c) : "memory");)
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float acc = lp[0];
+  for (int i = 0; i < 8; ++i) acc += a[i].x + a[i].y + s[i];
+  if (acc == 12345.678f) sink[0] = acc;
+  if ((threadIdx.x & 63) == 0) out[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int KIND>
+void run(const char* name, int per_iter) {
+  unsigned long long* d; float* sink;
+  hipMalloc(&d, 256 * 16 * 8); hipMalloc(&sink, 4);
+  for (int threads : {256, 512, 1024}) {   // 1, 2, 4 waves per SIMD (one block per CU, all 256 CUs)
+    const int iters = 200;
+    hipMemset(d, 0, 256 * 16 * 8);
+    bench<KIND><<<256, threads, 20480>>>(d, sink, iters);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(256 * 16);
+    hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+    double sum = 0; int n = 0;
+    for (int b = 0; b < 256; ++b) for (int w = 0; w < threads / 64; ++w) { sum += (double)h[b * 16 + w]; ++n; }
+    const double cyc = sum / n / iters / per_iter;   // cycles of wave time per instruction
+    printf("%-34s %d waves/SIMD: %6.2f cycles per wave-instruction, %6.2f per SIMD slot\n", name, threads / 256, cyc, cyc / (threads / 256));
+  }
+  hipFree(d); hipFree(sink);
+}
+
+int main() {
+  run<1>("v_fma_f32", 64); run<0>("v_pk_fma_f32", 64); run<3>("v_add_f32", 64); run<2>("v_pk_add_f32", 64);
+  run<4>("v_pk_mul_f32 op_sel", 64); run<5>("ds_write_b64 (8 + wait)", 64); run<6>("ds_read_b64 (8 + wait)", 64);
+  run<7>("2 ds_write_b64 + 8 v_pk_fma", 80);
+  return 0;
+}
