@@ -34,7 +34,14 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
   // ---- magnitudes to LDS in natural bin order ----
   V* mag = reinterpret_cast<V*>(fbase + L::MAG_OFF);
   V* pb = reinterpret_cast<V*>(fbase + L::PB_OFF);
-  V* bs = reinterpret_cast<V*>(fbase + L::BS_OFF) + 1;  // bs[-1] .. bs[N/256]
+  V* bs = reinterpret_cast<V*>(fbase + L::BS_OFF) + L::BS_HALO;  // bs[-16] .. bs[N/16 + 15]
+  // Block length of the block-relative prefixes: 256 cells, or -- fp32, every summed run (window, CASH sub-window) at
+  // most 16 cells long -- 16 cells = the thread's own chunk.  A window sum is a difference of two prefixes and its
+  // rounding error scales with the prefix, not with the window: with 256-cell blocks an 8-cell window needed a 2.5x
+  // looser tolerance than every other geometry.  A run of <= 16 cells crosses at most one 16-cell block edge.
+  const int run_len = rg.cfar_mode == 3 ? rg.sub_window : rg.R;
+  const bool short_blocks = !FIXED && run_len <= 16;
+  const int sh = short_blocks ? 4 : 8;
   uint32_t* det_cnt = reinterpret_cast<uint32_t*>(fbase + L::DET_OFF);
   uint2* det_stage = reinterpret_cast<uint2*>(fbase + L::DET_OFF + 8);
   const bool wrap = rg.edge != 0;
@@ -63,7 +70,7 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
     inc += row_shr<2>(inc);
     inc += row_shr<4>(inc);
     inc += row_shr<8>(inc);
-    const V exc = row_shr<1>(inc);
+    const V exc = short_blocks ? V(0) : row_shr<1>(inc);
     const int p0 = pb_slot(16 * tau);
 #pragma unroll
     for (int e = 0; e < 16; ++e) pb[p0 + e] = exc + loc[e];
@@ -78,7 +85,11 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
 #pragma unroll
       for (int e = 0; e < 16; ++e) pb[pl + e] = wrap ? exc + loc[e] : V(0);
     }
-    if ((tau & 15) == 15) {
+    if (short_blocks) {  // one block per thread: its total, and the halo images of the first / last 16 blocks
+      bs[tau] = acc;
+      if (tau < 16) bs[tau + T] = wrap ? acc : V(0);
+      if (tau >= T - 16) bs[tau - T] = wrap ? acc : V(0);
+    } else if ((tau & 15) == 15) {
       const int blk = tau >> 4;
       bs[blk] = inc;
       if (blk == N / 256 - 1) bs[-1] = wrap ? inc : V(0);
@@ -117,11 +128,11 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
       for (int j = 0; j < 16; ++j) {
         int bu0, bu1;
         bool c0, c1;
-        if constexpr (T % 256 == 0) {  // block of cell k is a per-thread constant + j T/256
-          bu0 = (xu0 >> 8) + j * (T / 256);
-          bu1 = (xu1 >> 8) + j * (T / 256);
-          c0 = (xv0 >> 8) != (xu0 >> 8);
-          c1 = (xv1 >> 8) != (xu1 >> 8);
+        if (T % 256 == 0 || short_blocks) {  // block of cell k is a per-thread constant + j T / block (T is a multiple of 16)
+          bu0 = (xu0 >> sh) + j * (T >> sh);
+          bu1 = (xu1 >> sh) + j * (T >> sh);
+          c0 = (xv0 >> sh) != (xu0 >> sh);
+          c1 = (xv1 >> sh) != (xu1 >> sh);
         } else {
           bu0 = (xu0 + T * j) >> 8;
           bu1 = (xu1 + T * j) >> 8;
@@ -146,7 +157,7 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
             for (int s0 = 0; s0 + rg.sub_window <= R; s0 += rg.sub_window) {
               const int u = a + s0, v = u + rg.sub_window;
               V ss = pb[pb_slot(v)] - pb[pb_slot(u)];
-              if ((v >> 8) != (u >> 8)) ss += bs[u >> 8];
+              if ((v >> sh) != (u >> sh)) ss += bs[u >> sh];
               b = first ? ss : (ss > b ? ss : b);
               first = false;
             }

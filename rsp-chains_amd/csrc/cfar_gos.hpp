@@ -162,13 +162,41 @@ __device__ __forceinline__ V select_bitonic(const V (&x)[SZ], int k) {
   }
 }
 
+// k-th smallest (0-based, K a compile-time constant) of the union of two ASCENDING sequences b[NB] and d[ND]: the
+// smallest v = max(b[i], d[j]) over the splits i + j = K - 1 (b[-1] = d[-1] = -infinity, i.e. i = -1 contributes d[K]
+// and j = -1 b[K]): b[0..i] and d[0..j] are K + 1 values <= v, and at the split that takes exactly the K + 1 smallest
+// values v IS the statistic.  At most min(NB, ND) + 1 terms: for two 16-cell parts and K = 24 eight max + seven min
+// = 15 operations, against the 31 of the half-cleaner cascade above.
+template <int K, int NB, int ND, typename V, typename VB, typename VD>
+__device__ __forceinline__ V select_split_k(const VB& b, const VD& d) {
+  constexpr int ILO = K - ND > -1 ? K - ND : -1, IHI = NB - 1 < K ? NB - 1 : K, NT = IHI - ILO + 1;
+  static_assert(K >= 0 && K < NB + ND && NT >= 1, "0 <= K < NB + ND");
+  V t[NT];
+#pragma unroll
+  for (int i = ILO; i <= IHI; ++i) {
+    const int j = K - 1 - i;
+    if (i < 0) t[i - ILO] = d[K];
+    else if (j < 0) t[i - ILO] = b[K];
+    else t[i - ILO] = vmax1<V>(b[i], d[j]);
+  }
+#pragma unroll
+  for (int w = 1; w < NT; w <<= 1) {  // pairwise: a tree log2(NT) deep instead of a chain of NT dependent minima
+#pragma unroll
+    for (int i = 0; i + w < NT; i += 2 * w) t[i] = vmin1<V>(t[i], t[i + w]);
+  }
+  return t[0];
+}
+
 // The same statistics with the window SPLIT: the RUN windows of a thread (starts a0 .. a0 + RUN - 1) all contain
 // the cells B = [a0 + RUN - 1, a0 + R); only the other RUN - 1 cells D change from start to start (one leaves at
 // the front, one enters past B).  B is sorted once, D is kept sorted with the delete + insert slide -- 3 (RUN - 1)
 // operations per start instead of 3 R -- and the order statistic is selected from the bitonic sequence
 // [B ascending | D descending] with R - 1 min / max.  R = 32, RUN = 17: two 16-element sorts + 16 x 48 + 17 x 31 =
 // 1547 operations per 17 starts against 382 + 16 x 94 = 1886 with one 32-cell sorted window.
-template <typename V, int R, int RUN>
+// KC >= 0: indexLagg = indexLead = KC known at compile time (the launcher instantiates the usual choices, R / 2 and
+// 3 R / 4): the selection is select_split_k on the two sorted parts, 15 operations at R = 32, K = 24 -- 1275 per 17
+// starts.  (As a switch over a run-time index INSIDE the loop the same selection lost its gain to the compare chain.)
+template <typename V, int R, int RUN, int KC = -1>
 __device__ __forceinline__ void gos_stage_split(const V* mag, V* o1, V* o2, int tau, int G, int idx_lagg, int idx_lead) {
   constexpr int ND = RUN - 1, NB = R - ND;
   static_assert(NB >= 1 && (R & (R - 1)) == 0, "a common part and a power-of-two window");
@@ -182,6 +210,20 @@ __device__ __forceinline__ void gos_stage_split(const V* mag, V* o1, V* o2, int 
   sort_window<V, ND>(d);
   sort_window<V, NB>(b);
   const bool two = idx_lagg != idx_lead;
+  if constexpr (KC >= 0) {
+    // the cell that leaves and the cell that enters are read ONE step ahead: the slide is a chain of asm statements
+    // the scheduler cannot hoist a load over, so a read issued inside the step would expose its LDS latency 16 times
+    V old = mag[pad(a0 + kHalo)], nw = mag[pad(a0 + R + kHalo)];
+#pragma unroll 1
+    for (int st = 0; st < RUN; ++st) {
+      const V old_n = mag[pad(a0 + st + 1 + kHalo)], nw_n = mag[pad(a0 + st + 1 + R + kHalo)];  // inside the 256-cell halo
+      o1[pad(RUN * tau + st)] = select_split_k<KC, NB, ND, V>(b, d);
+      if (st + 1 < RUN) slide<V, ND>(d, old, nw);
+      old = old_n;
+      nw = nw_n;
+    }
+    return;
+  }
 #pragma unroll 1
   for (int st = 0; st < RUN; ++st) {
     V seq[R];  // [B ascending | D descending]
@@ -204,7 +246,10 @@ __device__ __forceinline__ void gos_stage_split(const V* mag, V* o1, V* o2, int 
 // BIG = the 64-cell window: its sorted window alone is 64 + 63 registers, so it is a kernel of its own -- as one path
 // of a common kernel it set the register count (141 + scratch) and with it the occupancy (one 512-thread workgroup
 // per CU at 8192 points) of every other window size.
-template <int M, bool FIXED, bool BIG, int FX>
+// KIND: 0 = windows up to 32 cells; 1 = the 64-cell window on the split path (17 starts per thread: every frame size
+// >= 1024); 2 = the 64-cell window, one sorted 64-cell vector slid over any number of starts (256 / 512-point frames:
+// its run-time pick of a 64-register vector goes through scratch memory, 640 B -- kept out of the other two).
+template <int M, bool FIXED, int KIND, int FX>
 __global__ void __launch_bounds__(wg_size(M))
 chain1d_gos_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t n_frames,
                    ChainRegs rg, GosLayout lay, const void* __restrict__ tw,
@@ -243,16 +288,22 @@ chain1d_gos_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint
     if (h == 31) mag[pad(N + kHalo + kHalo)] = wrap ? mag[pad(kHalo + kHalo)] : V(0);
   }
   __syncthreads();
-  if constexpr (BIG) {
-    if (lay.run == 17 && RSP_GOS_SPLIT) gos_stage_split<V, 64, 17>(mag, o1, o2, tau, rg.G, rg.idx_lagg, rg.idx_lead);
-    else gos_stage<V, 64>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead);
+  if (hk.off(1)) {  // (side builds) no order-statistic stage: what the rest of the kernel costs
+  } else if constexpr (KIND == 1) {
+    gos_stage_split<V, 64, 17>(mag, o1, o2, tau, rg.G, rg.idx_lagg, rg.idx_lead);
+  } else if constexpr (KIND == 2) {
+    gos_stage<V, 64>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead);
   } else {
     switch (rg.R) {
       case 4: gos_stage<V, 4>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead); break;
       case 8: gos_stage<V, 8>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead); break;
       case 16: gos_stage<V, 16>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead); break;
       default:
-        if (lay.run == 17 && RSP_GOS_SPLIT) gos_stage_split<V, 32, 17>(mag, o1, o2, tau, rg.G, rg.idx_lagg, rg.idx_lead);
+        if (lay.run == 17 && RSP_GOS_SPLIT) {
+          if (rg.idx_lagg == rg.idx_lead && rg.idx_lagg == 24) gos_stage_split<V, 32, 17, 24>(mag, o1, o2, tau, rg.G, 24, 24);
+          else if (rg.idx_lagg == rg.idx_lead && rg.idx_lagg == 16) gos_stage_split<V, 32, 17, 16>(mag, o1, o2, tau, rg.G, 16, 16);
+          else gos_stage_split<V, 32, 17>(mag, o1, o2, tau, rg.G, rg.idx_lagg, rg.idx_lead);
+        }
         else gos_stage<V, 32>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead);
         break;
     }

@@ -27,12 +27,17 @@ template <bool SMALL> struct QuadHalo {
 };
 constexpr int kQHalo = QuadHalo<false>::MAG;     // the largest window the quad tail serves: R + G + 4 <= 144
 
-template <int M, bool SMALL>
+// SHORTW: the prefixes are relative to blocks of 16 cells instead of 256 (fp32, windows of at most 16 cells: a window
+// sum is a difference of two prefixes, and its rounding error scales with the length of the prefix, not of the window:
+// against 256-cell blocks an 8-cell window needed a 2.5x looser tolerance than every other geometry).
+template <int M, bool SMALL, bool SHORTW = false>
 struct QuadLds {
   static constexpr int N = 1 << M, QH = QuadHalo<SMALL>::MAG, PBH = QuadHalo<SMALL>::PB;
+  static constexpr int BSH = SHORTW ? 4 : 8;          // log2 of the block length
+  static constexpr int BS_HALO = SHORTW ? PBH / 16 : 1;  // block totals kept on either side of the frame
   static constexpr int MAG_SLOTS = 16 + N + QH;      // cell x in [-16, N + QH) at x + 16
   static constexpr int PB_SLOTS = N + 2 * PBH;       // cell x in [-PBH, N + PBH) at x + PBH
-  static constexpr int BS_SLOTS = N / 256 + 3;       // blocks -1 .. N/256, + one slot that holds 0
+  static constexpr int BS_SLOTS = (N >> BSH) + 2 * BS_HALO + 1;  // blocks -BS_HALO .. (N >> BSH) + BS_HALO - 1, + one slot that holds 0
   static constexpr int MAG_OFF = 0;
   static constexpr int PB_OFF = MAG_OFF + 4 * MAG_SLOTS;
   static constexpr int BS_OFF = PB_OFF + 4 * PB_SLOTS;
@@ -87,20 +92,33 @@ __device__ __forceinline__ V seg_scan(V v) {
 // every thread has passed the first barrier below.  Barriers are the hook policy's (Hooks::barrier(): __syncthreads()
 // in the plain kernels; the pipelined kernel of chain1d_pipe.hip keeps LDS-DMA loads in flight across the tail and
 // brings a barrier without a vector-memory wait).
-template <int M, bool FIXED, bool SMALL, typename V, typename Hooks>
+// inclusive scan over aligned groups of 4 lanes (16 cells): row shifts by 1 and 2, kept out of the lanes whose source
+// sits in the neighbouring group
+__device__ __forceinline__ float seg4_scan(float v, unsigned tid) {
+  const float a = dpp_v<0x111, 0xf, true>(v);
+  v += (tid & 3u) ? a : 0.0f;
+  const float b = dpp_v<0x112, 0xf, true>(v);
+  v += (tid & 2u) ? b : 0.0f;
+  return v;
+}
+
+template <int M, bool FIXED, bool SMALL, bool SHORTW = false, typename V, typename Hooks>
 __device__ __forceinline__ void quad_tail(unsigned char* fbase, const V (&mg)[16], int tau, uint32_t frame, bool live,
                                           const ChainRegs& rg, uint32_t* __restrict__ out,
                                           uint32_t* __restrict__ fcount, uint2* __restrict__ fdet, Hooks& hk) {
   constexpr int N = 1 << M, T = threads_per_frame(M);
   constexpr int WD = T < 64 ? T : 64;  // lanes of a wave that belong to one frame
   constexpr int SPB = 64 / WD;         // lane segments (values of e) per 256-cell block
-  using L = QuadLds<M, SMALL>;
-  constexpr int QH = L::QH, PBH = L::PBH;
+  using L = QuadLds<M, SMALL, SHORTW>;
+  constexpr int QH = L::QH, PBH = L::PBH, BSH = L::BSH, BH = L::BS_HALO;
+  constexpr int NB = N >> BSH;          // blocks per frame
+  constexpr int ZS = NB + BH;           // the slot that holds 0: "no block total to add"
   using V4 = typename Vec4<V>::type;
+  static_assert(!SHORTW || (!FIXED && SMALL), "16-cell blocks: fp32, windows of at most 16 cells");
 
   V* mag = reinterpret_cast<V*>(fbase + L::MAG_OFF) + 16;   // mag[x], x in [-16, N + QH)
   V* pb = reinterpret_cast<V*>(fbase + L::PB_OFF) + PBH;    // pb[x], x in [-PBH, N + PBH)
-  V* bs = reinterpret_cast<V*>(fbase + L::BS_OFF) + 1;      // bs[-1] .. bs[N/256], bs[N/256 + 1] = 0
+  V* bs = reinterpret_cast<V*>(fbase + L::BS_OFF) + BH;     // bs[-BH] .. bs[NB + BH - 1], bs[ZS] = 0
   uint32_t* det_cnt = reinterpret_cast<uint32_t*>(fbase + L::DET_OFF);
   uint2* det_stage = reinterpret_cast<uint2*>(fbase + L::DET_OFF + 8);
   const bool wrap = rg.edge != 0;
@@ -125,7 +143,7 @@ __device__ __forceinline__ void quad_tail(unsigned char* fbase, const V (&mg)[16
   }
   if (tau == 0) {
     *det_cnt = 0u;
-    bs[N / 256 + 1] = V(0);  // the "no block total" slot of the window fix-ups
+    bs[ZS] = V(0);  // the "no block total" slot of the window fix-ups
   }
   Hooks::barrier();
   hk.stamp(8);
@@ -143,7 +161,8 @@ __device__ __forceinline__ void quad_tail(unsigned char* fbase, const V (&mg)[16
       p1[e] = mq[e][0];
       p2[e] = p1[e] + mq[e][1];
       p3[e] = p2[e] + mq[e][2];
-      inc[e] = seg_scan<WD, V>(p3[e] + mq[e][3]);
+      if constexpr (SHORTW) inc[e] = seg4_scan(p3[e] + mq[e][3], threadIdx.x);
+      else inc[e] = seg_scan<WD, V>(p3[e] + mq[e][3]);
     }
     V tot[4];
 #pragma unroll
@@ -151,7 +170,7 @@ __device__ __forceinline__ void quad_tail(unsigned char* fbase, const V (&mg)[16
       const int q = tau + T * e;  // quad index; block q >> 6, position q & 63
       tot[e] = inc[e];            // inclusive through this quad, within the lane segment
       V exc = inc[e] - (p3[e] + mq[e][3]);
-      if constexpr (SPB > 1) {    // a block spans SPB values of e (frames of 256 / 512 points): carry the earlier ones
+      if constexpr (SPB > 1 && !SHORTW) {  // a block spans SPB values of e (frames of 256 / 512 points): carry the earlier ones
         V carry = V(0);
 #pragma unroll
         for (int e2 = 0; e2 < 4; ++e2) {
@@ -172,6 +191,19 @@ __device__ __forceinline__ void quad_tail(unsigned char* fbase, const V (&mg)[16
       if (q >= N / 4 - PBH / 4) *reinterpret_cast<V4*>(pb + 4 * q - N) = wrap ? pq : zero4;
       if (q == N / 4 - 1) mag[-1] = wrap ? mq[e][3] : V(0);
     }
+    if constexpr (SHORTW) {
+      // block totals of the 16-cell blocks: the lane that holds a block's fourth quad, + the halo images
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int q = tau + T * e;
+        if ((q & 3) == 3) {
+          const int blk = q >> 2;
+          bs[blk] = tot[e];
+          if (blk < BH) bs[blk + NB] = wrap ? tot[e] : V(0);
+          if (blk >= NB - BH) bs[blk - NB] = wrap ? tot[e] : V(0);
+        }
+      }
+    } else {
     // block totals: the lane that holds a block's last quad (for T >= 64 the same lane for every e)
     auto block_total = [&](int e) {
       const int blk = (tau + T * e) >> 6;
@@ -188,6 +220,7 @@ __device__ __forceinline__ void quad_tail(unsigned char* fbase, const V (&mg)[16
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         if (((tau + T * e) & 63) == 63) block_total(e);
+    }
     }
   }
   Hooks::barrier();
@@ -207,29 +240,28 @@ __device__ __forceinline__ void quad_tail(unsigned char* fbase, const V (&mg)[16
     const V* mc = mag + k00;
     constexpr int ES = 4 * T;  // cells between a thread's consecutive quads
     const float kA = rg.linear ? rg.div_f * rg.scaler_f : rg.div_f, kB = rg.linear ? 0.0f : rg.scaler_f;
-    // block (256 cells) of the two window starts, and whether the window ends in the next block: then
+    // block (256 cells; 16 with SHORTW) of the two window starts, and whether the window ends in the next block: then
     // the start block's total is added.  A quad never straddles a block, so this is per quad; the
     // "no" case reads the slot that holds 0, which keeps the read unconditional (no divergent branch).
-    constexpr int ZS = N / 256 + 1;
     auto cells = [&](auto mode_c, auto group_c) {
       constexpr int MODE = decltype(mode_c)::value;
       constexpr bool GROUP = decltype(group_c)::value;
       int i0[4], i1[4];
-      if constexpr ((4 * T) % 256 == 0) {  // a thread's quads sit whole blocks apart: same case for all four
-        const int bu0 = (k00 - G - R) >> 8, bu1 = (k00 + G) >> 8;
-        const bool z0 = ((k00 - G) >> 8) == bu0, z1 = ((k00 + G + R) >> 8) == bu1;
+      if constexpr ((4 * T) % (1 << BSH) == 0) {  // a thread's quads sit whole blocks apart: same case for all four
+        const int bu0 = (k00 - G - R) >> BSH, bu1 = (k00 + G) >> BSH;
+        const bool z0 = ((k00 - G) >> BSH) == bu0, z1 = ((k00 + G + R) >> BSH) == bu1;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          i0[e] = z0 ? ZS : bu0 + (4 * T / 256) * e;
-          i1[e] = z1 ? ZS : bu1 + (4 * T / 256) * e;
+          i0[e] = z0 ? ZS : bu0 + ((4 * T) >> BSH) * e;
+          i1[e] = z1 ? ZS : bu1 + ((4 * T) >> BSH) * e;
         }
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int k0 = k00 + 4 * T * e;
-          const int bu0 = (k0 - G - R) >> 8, bu1 = (k0 + G) >> 8;
-          i0[e] = ((k0 - G) >> 8) != bu0 ? bu0 : ZS;
-          i1[e] = ((k0 + G + R) >> 8) != bu1 ? bu1 : ZS;
+          const int bu0 = (k0 - G - R) >> BSH, bu1 = (k0 + G) >> BSH;
+          i0[e] = ((k0 - G) >> BSH) != bu0 ? bu0 : ZS;
+          i1[e] = ((k0 + G + R) >> BSH) != bu1 ? bu1 : ZS;
         }
       }
 #pragma unroll
@@ -380,13 +412,13 @@ __device__ __forceinline__ void quad_tail(unsigned char* fbase, const V (&mg)[16
   }
 }
 
-template <int M, bool FIXED, int FX, bool SMALL>
+template <int M, bool FIXED, int FX, bool SMALL, bool SHORTW = false>
 __global__ void __launch_bounds__(wg_size(M))
 chain1d_quad_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t n_frames,
                     ChainRegs rg, const void* __restrict__ tw, const int16_t* __restrict__ log_lut,
                     uint32_t* __restrict__ fcount, uint2* __restrict__ fdet) {
   constexpr int T = threads_per_frame(M), FPW = frames_per_wg(M);
-  using L = QuadLds<M, SMALL>;
+  using L = QuadLds<M, SMALL, SHORTW>;
   using V = typename std::conditional<FIXED, int, float>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -404,7 +436,7 @@ chain1d_quad_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uin
   front_end<M, FIXED, V, FX>(in, hk.off(5) ? (frame & 63u) : frame, live, tau, fbase, rg, tw, log_lut,
                              reinterpret_cast<uint32_t*>(smem + (size_t)L::BYTES * FPW), mg, hk);
   hk.stamp(7);
-  quad_tail<M, FIXED, SMALL>(fbase, mg, tau, frame, live, rg, hk.off(6) ? nullptr : out, fcount, fdet, hk);
+  quad_tail<M, FIXED, SMALL, SHORTW>(fbase, mg, tau, frame, live, rg, hk.off(6) ? nullptr : out, fcount, fdet, hk);
 }
 
 }  // namespace rsp

@@ -38,9 +38,18 @@ static hipError_t launch_gos(const Chain1dLaunch& a) {
   };
   return with_fx(a, [&](auto fx) -> hipError_t {
     constexpr int FX = decltype(fx)::value;
-    static LdsGrant g2[2];
-    return a.regs.R > 32 ? go(chain1d_gos_kernel<M, kPartFixed, true, FX>, g2[0])
-                         : go(chain1d_gos_kernel<M, kPartFixed, false, FX>, g2[1]);
+    static LdsGrant g3[3];
+    if (a.regs.R <= 32) return go(chain1d_gos_kernel<M, kPartFixed, 0, FX>, g3[0]);
+    // 64-cell window: run = 16 + ceil(16 (2 G + 65) / N) starts per thread -- always 17 from 4096 points up (G <= 63),
+    // never 17 up to 512 points, so each frame size instantiates only the kinds it can reach
+    const bool split = lay.run == 17 && RSP_GOS_SPLIT;
+    if constexpr (M >= 10) {
+      if (split) return go(chain1d_gos_kernel<M, kPartFixed, 1, FX>, g3[1]);
+    }
+    if constexpr (M <= 11) {
+      if (!split) return go(chain1d_gos_kernel<M, kPartFixed, 2, FX>, g3[2]);
+    }
+    return hipErrorInvalidValue;
   });
 }
 
@@ -50,18 +59,24 @@ static hipError_t launch_quad(const Chain1dLaunch& a) {
   const uint32_t grid = (a.n_frames + fpw - 1) / fpw;
   return with_fx(a, [&](auto fx) -> hipError_t {
     constexpr int FX = decltype(fx)::value;
-    auto go = [&](auto small_c, LdsGrant& granted) -> hipError_t {
-      constexpr bool SMALL = decltype(small_c)::value;
-      const size_t lds = QuadLds<M, SMALL>::BYTES * fpw + (kPartFixed ? QuadLds<M, SMALL>::ROM_BYTES : 0);
-      auto k = chain1d_quad_kernel<M, kPartFixed, FX, SMALL>;
+    auto go = [&](auto small_c, auto short_c, LdsGrant& granted) -> hipError_t {
+      constexpr bool SMALL = decltype(small_c)::value, SHORTW = decltype(short_c)::value;
+      using L = QuadLds<M, SMALL, SHORTW>;
+      const size_t lds = L::BYTES * fpw + (kPartFixed ? L::ROM_BYTES : 0);
+      auto k = chain1d_quad_kernel<M, kPartFixed, FX, SMALL, SHORTW>;
       hipError_t e = grant_lds(k, lds, a.device, granted);
       if (e != hipSuccess) return e;
       hipLaunchKernelGGL(k, dim3(grid), dim3(wg_size(M)), lds, a.stream, a.in, a.out, a.n_frames,
                          a.regs, a.twiddles, a.log_lut, a.frame_count, a.frame_det);
       return hipGetLastError();
     };
-    static LdsGrant g2[2];
-    return a.regs.R + a.regs.G + 4 <= QuadHalo<true>::MAG ? go(std::true_type{}, g2[0]) : go(std::false_type{}, g2[1]);
+    static LdsGrant g3[3];
+    // fp32 windows of at most 16 cells: prefixes relative to 16-cell blocks (QuadLds: SHORTW)
+    if constexpr (!kPartFixed) {
+      if (a.regs.R <= 16) return go(std::true_type{}, std::true_type{}, g3[2]);
+    }
+    return a.regs.R + a.regs.G + 4 <= QuadHalo<true>::MAG ? go(std::true_type{}, std::false_type{}, g3[0])
+                                                           : go(std::false_type{}, std::false_type{}, g3[1]);
   });
 }
 

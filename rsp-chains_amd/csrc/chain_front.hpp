@@ -24,7 +24,8 @@ namespace rsp {
 // After the FFT the frame's LDS is re-used for the CFAR working set (4-byte slots):
 //   mag : cell x in [-16, N+16)   at slot pad(x + 16)    (1-cell halo for peak grouping)
 //   pb  : cell x in [-256, N+256] at slot pad(x + 256)   block-relative exclusive prefix
-//   bs  : block b in [-1, N/256]  at slot b + 1          block totals
+//   bs  : block b in [-16, N/16 + 16) at slot b + 16     block totals (blocks of 256 cells: only b in [-1, N/256];
+//                                                        blocks of 16 cells for fp32 windows of at most 16 cells)
 //   det : detection staging (count + kFrameDetCap x {bin, word})
 // The halos hold zeros (edge = zero) or wrapped copies (edge = wrap), so the
 // per-cell CFAR code needs no clamping and no edge branches.
@@ -36,7 +37,8 @@ struct FrameLds {
   static constexpr int PADN = fft_image_slots(M);
   static constexpr int MAG_SLOTS = pad_slots(N + 32) + 1;
   static constexpr int PB_SLOTS = pad_slots(N + 2 * kHalo) + 2;
-  static constexpr int BS_SLOTS = N / 256 + 3;  // blocks -1 .. N/256, + one slot that holds 0
+  static constexpr int BS_HALO = 16;            // block totals kept on either side of the frame (16-cell blocks: 256 cells)
+  static constexpr int BS_SLOTS = N / 16 + 2 * BS_HALO + 1;
   static constexpr int MAG_OFF = 0;
   static constexpr int PB_OFF = MAG_OFF + 4 * MAG_SLOTS;
   static constexpr int BS_OFF = PB_OFF + 4 * PB_SLOTS;

@@ -83,7 +83,7 @@ def test_f32_use_bit_reverse_false(gpu, n):
     x = R.stimulus.chirp_frames(4, n, seed=9 + n)
     got = run(params, rt, x)
     thr, peak, margin, mag = O.chain_f32(x, oracle_fcfg(params, rt), want_mag=True)
-    compare_f32(got, thr, peak, margin, mag, rtol=5e-5)   # 8-cell windows (see test_cash_mode)
+    compare_f32(got, thr, peak, margin, mag)
 
 
 @pytest.mark.parametrize("npts,n,alg,guard", SHAPES)

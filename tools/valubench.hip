@@ -39,6 +39,25 @@ __global__ void __launch_bounds__(1024) bench(unsigned long long* out, float* si
       REP8(asm volatile("v_pk_mul_f32 %0, %0, %8 op_sel_hi:[0,1]\n v_pk_mul_f32 %1, %1, %8 op_sel_hi:[0,1]\n v_pk_mul_f32 %2, %2, %8 op_sel_hi:[0,1]\n v_pk_mul_f32 %3, %3, %8 op_sel_hi:[0,1]\n"
                         "v_pk_mul_f32 %4, %4, %8 op_sel_hi:[0,1]\n v_pk_mul_f32 %5, %5, %8 op_sel_hi:[0,1]\n v_pk_mul_f32 %6, %6, %8 op_sel_hi:[0,1]\n v_pk_mul_f32 %7, %7, %8 op_sel_hi:[0,1]"
                         : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b));)
+    } else if constexpr (KIND == 8) {  // 8 x (v_cmp_lt_f32 -> SGPR pair) then 8 x v_cndmask by those masks: the GOS slide's pair
+      REP8(asm volatile("v_cmp_lt_f32_e64 s[20:21], %0, %8\n v_cmp_lt_f32_e64 s[22:23], %1, %8\n v_cmp_lt_f32_e64 s[24:25], %2, %8\n v_cmp_lt_f32_e64 s[26:27], %3, %8\n"
+                        "v_cmp_lt_f32_e64 s[28:29], %4, %8\n v_cmp_lt_f32_e64 s[30:31], %5, %8\n v_cmp_lt_f32_e64 s[32:33], %6, %8\n v_cmp_lt_f32_e64 s[34:35], %7, %8\n"
+                        "v_cndmask_b32_e64 %0, %0, %1, s[20:21]\n v_cndmask_b32_e64 %1, %1, %2, s[22:23]\n v_cndmask_b32_e64 %2, %2, %3, s[24:25]\n v_cndmask_b32_e64 %3, %3, %4, s[26:27]\n"
+                        "v_cndmask_b32_e64 %4, %4, %5, s[28:29]\n v_cndmask_b32_e64 %5, %5, %6, s[30:31]\n v_cndmask_b32_e64 %6, %6, %7, s[32:33]\n v_cndmask_b32_e64 %7, %7, %0, s[34:35]"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x)
+                        : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35");)
+    } else if constexpr (KIND == 9) {  // v_med3_f32
+      REP8(asm volatile("v_med3_f32 %0, %0, %8, %9\n v_med3_f32 %1, %1, %8, %9\n v_med3_f32 %2, %2, %8, %9\n v_med3_f32 %3, %3, %8, %9\n"
+                        "v_med3_f32 %4, %4, %8, %9\n v_med3_f32 %5, %5, %8, %9\n v_med3_f32 %6, %6, %8, %9\n v_med3_f32 %7, %7, %8, %9"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x), "v"(c.x));)
+    } else if constexpr (KIND == 10) {  // v_min_f32 / v_max_f32
+      REP8(asm volatile("v_min_f32 %0, %0, %8\n v_max_f32 %1, %1, %8\n v_min_f32 %2, %2, %8\n v_max_f32 %3, %3, %8\n"
+                        "v_min_f32 %4, %4, %8\n v_max_f32 %5, %5, %8\n v_min_f32 %6, %6, %8\n v_max_f32 %7, %7, %8"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x));)
+    } else if constexpr (KIND == 11) {  // ds_read_b32 / ds_write_b32 pairs (the GOS loop's o1 write + two reads)
+      REP8(asm volatile("ds_read_b32 %0, %8\n ds_read_b32 %1, %8 offset:1024\n ds_write_b32 %8, %2 offset:2048\n ds_read_b32 %3, %8 offset:3072\n"
+                        "ds_read_b32 %4, %8 offset:4096\n ds_write_b32 %8, %5 offset:5120\n ds_read_b32 %6, %8 offset:6144\n ds_read_b32 %7, %8 offset:7168\n s_waitcnt lgkmcnt(0)"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"((unsigned)(threadIdx.x & 255) * 4u) : "memory");)
     } else if constexpr (KIND == 5) {  // ds_write_b64, lane-contiguous
       REP8(asm volatile("ds_write_b64 %0, %1\n ds_write_b64 %0, %2 offset:2048\n ds_write_b64 %0, %3 offset:4096\n ds_write_b64 %0, %4 offset:6144\n"
                         "ds_write_b64 %0, %5 offset:8192\n ds_write_b64 %0, %6 offset:10240\n ds_write_b64 %0, %7 offset:12288\n ds_write_b64 %0, %8 offset:14336\n s_waitcnt lgkmcnt(0)"
@@ -83,5 +102,6 @@ int main() {
   run<1>("v_fma_f32", 64); run<0>("v_pk_fma_f32", 64); run<3>("v_add_f32", 64); run<2>("v_pk_add_f32", 64);
   run<4>("v_pk_mul_f32 op_sel", 64); run<5>("ds_write_b64 (8 + wait)", 64); run<6>("ds_read_b64 (8 + wait)", 64);
   run<7>("2 ds_write_b64 + 8 v_pk_fma", 80);
+  run<8>("v_cmp->SGPR + v_cndmask (8 + 8)", 128); run<9>("v_med3_f32", 64); run<10>("v_min/v_max_f32", 64); run<11>("ds_read/write_b32 (6 + 2, wait)", 64);
   return 0;
 }
