@@ -268,7 +268,7 @@ chain1d_gos_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint
   SideHooks hk;
   hk.init(rg);
   front_end<M, FIXED, V, FX>(in, frame, live, tau, fbase, rg, tw, log_lut,
-                             reinterpret_cast<uint32_t*>(smem + (size_t)lay.frame_bytes * FPW), mg, hk);
+                             reinterpret_cast<uint2*>(smem + (size_t)lay.frame_bytes * FPW), mg, hk);
 
   V* mag = reinterpret_cast<V*>(fbase);  // cell x in [-256, N + 256] at slot pad(x + 256)
   V* o1 = reinterpret_cast<V*>(fbase + lay.o1_off);

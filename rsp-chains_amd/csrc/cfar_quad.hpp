@@ -45,7 +45,7 @@ struct QuadLds {
   static constexpr int CFAR_BYTES = DET_OFF + 8 + 8 * kFrameDetCap;
   static constexpr int FFT_BYTES = 8 * fft_image_slots(M);
   static constexpr int BYTES = ((CFAR_BYTES > FFT_BYTES ? CFAR_BYTES : FFT_BYTES) + 15) & ~15;
-  static constexpr int ROM_BYTES = 4 * (N / 2);
+  static constexpr int ROM_BYTES = 8 * (N / 2);
 };
 
 // the geometry the quad tail is built for (host-side dispatch, launch_m)
@@ -434,7 +434,7 @@ chain1d_quad_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uin
   hk.stamp(0);
 // (side builds, -DRSP_ABLATE: mask bit 5 reads 64 L2-resident frames instead of the batch, bit 6 drops the word stores)
   front_end<M, FIXED, V, FX>(in, hk.off(5) ? (frame & 63u) : frame, live, tau, fbase, rg, tw, log_lut,
-                             reinterpret_cast<uint32_t*>(smem + (size_t)L::BYTES * FPW), mg, hk);
+                             reinterpret_cast<uint2*>(smem + (size_t)L::BYTES * FPW), mg, hk);
   hk.stamp(7);
   quad_tail<M, FIXED, SMALL, SHORTW>(fbase, mg, tau, frame, live, rg, hk.off(6) ? nullptr : out, fcount, fdet, hk);
 }

@@ -46,7 +46,7 @@ struct FrameLds {
   static constexpr int CFAR_BYTES = DET_OFF + 8 + 8 * kFrameDetCap;
   static constexpr int FFT_BYTES = 8 * PADN;             // f32x2 per slot (FIXED16 uses 4 B)
   static constexpr int BYTES = ((CFAR_BYTES > FFT_BYTES ? CFAR_BYTES : FFT_BYTES) + 15) & ~15;
-  static constexpr int ROM_BYTES = 4 * (N / 2);  // FIXED16: LDS copy of the Q2.14 twiddle ROM, per workgroup
+  static constexpr int ROM_BYTES = 8 * (N / 2);  // FIXED16: LDS copy of the Q2.14 twiddle ROM ({W1, W2} per twiddle: fx_rom_entry), per workgroup
 };
 
 __device__ __forceinline__ int mag_slot(int x) { return pad(x + 16); }
@@ -124,7 +124,7 @@ template <int M, bool FIXED, typename V, int FX, typename Hooks>
 __device__ __forceinline__ void front_end(const void* __restrict__ in, uint32_t frame, bool live, int tau,
                                           unsigned char* fbase, const ChainRegs& rg,
                                           const void* __restrict__ tw,
-                                          const int16_t* __restrict__ log_lut, uint32_t* rom,
+                                          const int16_t* __restrict__ log_lut, uint2* rom,
                                           V (&mg)[16], Hooks& hk) {
   constexpr int N = 1 << M;
   constexpr int W = plan_w(M, 0), LO = plan_lo(M, 0);
@@ -172,7 +172,7 @@ __device__ __forceinline__ void front_end(const void* __restrict__ in, uint32_t 
       }
     }
     // twiddle ROM -> LDS once per workgroup (the sample loads above are already in flight)
-    for (int i = threadIdx.x; i < N / 2; i += wg_size(M)) rom[i] = twq[i];
+    for (int i = threadIdx.x; i < N / 2; i += wg_size(M)) rom[i] = fx_rom_entry(twq[i]);
     __syncthreads();
     fft_fx_frame<M, FX>(xr, xi, tau, fbase, rom, rg);
     if (rg.mag_mode == 2) {

@@ -23,6 +23,9 @@ struct ChainRegs {
   // linear: thr = ((stat * scaler) << lin_shl) >> lin_shr   (one of the two is 0)
   // log:    thr = ((stat << log_shl) >> log_shr) + log_scaler
   int32_t lin_shl, lin_shr, log_shl, log_shr, log_scaler, tmax, tmin;
+  // 1: every statistic x scaler product of this configuration fits 31 bits (and both factors 24): the linear threshold
+  // is one v_mul_i32_i24 instead of a 64-bit multiply -- every reference configuration; 0: the general 64-bit form
+  int32_t fast32;
   // elaboration options every reference configuration leaves at their defaults (all 0 here)
   uint32_t keep_lsb_mask;  // bit s: FFTParams keepMSBorLSB(s) = false -- stage s drops its MSB instead of its LSB
   uint32_t expand_mask;    // bit s: FFTParams expandLogic(s) = 1 -- stage s keeps its (w+1)-bit results

@@ -402,15 +402,34 @@ __device__ __forceinline__ int trim_conv(int x) {
 }
 __device__ __forceinline__ int wrap16(int x) { return (int)(short)x; }
 
-// One register pass of the fixed-point FFT: radix-2 stages of field [LO, LO+W),
-// each with its own Q2.14 twiddle, (a+b) trimmed by 1 bit, (a-b)*W by 15 bits.
-// tw[k] = (wr << 16) | (wi & 0xffff) for W_N^k, k < N/2 -- an LDS copy of the ROM: for a given
-// stage and butterfly the index is (per-thread low << s) + compile-time constant, so every lookup
-// is one ds_read_b32 with an immediate offset.
+// One register pass of the fixed-point FFT: radix-2 stages of field [LO, LO+W), each with its own Q2.14 twiddle,
+// (a+b) trimmed by 1 bit, (a-b)*W by 15 bits -- the dataflow of the SDF pipeline.  The twiddle ROM is an LDS copy:
+// for a given stage and butterfly the index is (per-thread low << s) + compile-time constant, so every lookup is
+// one ds_read with an immediate offset.
+// The samples stay PACKED, {re[31:16], im[15:0]} (the beat format), through passes and exchanges.
+// A radix-2 butterfly of the SDF pipeline in ~21 VALU operations instead of 26 (and nothing around the exchanges):
+//   sum    a + b is 17 bits wide, (a + b) / 2 is not: floor((a + b) / 2) = (a & b) + ((a ^ b) >> 1) per 16-bit lane
+//          (v_and, v_xor, v_pk_ashrrev_i16, v_pk_add_u16), the rounding bit of the trim from (a ^ b) & 1
+//   diff   (a - b) W = a W - b W never forms the 17-bit difference: Re = a . {wr, -wi} - b . {wr, -wi},
+//          Im = a . {wi, wr} - b . {wi, wr} with v_dot2_i32_i16 (exact: |a . w| <= 2^30), the 15-bit trim on the
+//          32-bit results as before, the two 16-bit results packed by one v_perm_b32 (= the wrap to 16 bits)
+// and no unpacking / packing around the LDS exchanges.  The LDS ROM holds both operand forms of a twiddle,
+// rom[k] = {W1 = {wr, -wi}, W2 = {wi, wr}} (8 bytes; fx_rom_entry).  Bit-identical to pass_fx (same integers).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint2 fx_rom_entry(uint32_t w) {  // w = (wr << 16) | (wi & 0xffff), the global ROM's format
+  const uint32_t wr = w >> 16, wi = w & 0xffffu;
+  return make_uint2((wr << 16) | ((0u - wi) & 0xffffu), (wi << 16) | wr);
+}
+__device__ __forceinline__ int fx_rom_wr(uint2 e) { return (int)(short)(e.y & 0xffffu); }
+__device__ __forceinline__ int fx_rom_wi(uint2 e) { return (int)(short)(e.y >> 16); }
+
 template <int M, int P, bool CONV>
-__device__ __forceinline__ void pass_fx(int (&xr)[16], int (&xi)[16], int tau, const uint32_t* tw,
-                                        const ChainRegs& rg) {
+__device__ __forceinline__ void pass_fx_pk(uint32_t (&z)[16], int tau, const uint2* tw, const ChainRegs& rg) {
   constexpr int W = plan_w(M, P), LO = plan_lo(M, P), G = 16 >> W, T = threads_per_frame(M);
+  const s16x2 one2 = {1, 1};
+  // floor / half-up (CONV = false): the sum's rounding bit is (a ^ b) & 1 for half-up, 0 for floor
+  const uint32_t half_mask = rg.trim_bias1 ? 0x00010001u : 0u;
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     const int low = (g * T + tau) & ((1 << LO) - 1);
@@ -418,30 +437,36 @@ __device__ __forceinline__ void pass_fx(int (&xr)[16], int (&xi)[16], int tau, c
     for (int st = 0; st < W; ++st) {
       const int bl = W - 1 - st;
       const int s = M - 1 - (LO + bl);  // radix-2 stage number of this bit
-      const uint32_t* tws = tw + (low << s);
+      const uint2* tws = tw + (low << s);
 #pragma unroll
       for (int r0 = 0; r0 < (1 << W); ++r0) {
         if (r0 & (1 << bl)) continue;
         const int r1 = r0 | (1 << bl);
         const int jj = r0 & ((1 << bl) - 1);
-        const uint32_t w = tws[(jj << LO) << s];
-        const int wr = (int)(short)(w >> 16), wi = (int)(short)(w & 0xffffu);
+        const uint2 w = tws[(jj << LO) << s];
         const int ia = g * (1 << W) + r0, ib = g * (1 << W) + r1;
-        const int sr = xr[ia] + xr[ib], si = xi[ia] + xi[ib];
-        const int dr = xr[ia] - xr[ib], di = xi[ia] - xi[ib];
-        const int pr = __mul24(dr, wr) - __mul24(di, wi);
-        const int pi = __mul24(dr, wi) + __mul24(di, wr);
+        const uint32_t a = z[ia], b = z[ib];
+        const uint32_t x = a ^ b;
+        const s16x2 f = __builtin_bit_cast(s16x2, a & b) + (__builtin_bit_cast(s16x2, x) >> one2);  // floor((a + b) / 2)
+        const uint32_t fb = __builtin_bit_cast(uint32_t, f);
+        const uint32_t rb = CONV ? (x & fb & 0x00010001u) : (x & half_mask);  // convergent: a tie goes to the even neighbour
+        z[ia] = __builtin_bit_cast(uint32_t, f + __builtin_bit_cast(s16x2, rb));
+        const s16x2 av = __builtin_bit_cast(s16x2, a), bv = __builtin_bit_cast(s16x2, b);
+        const s16x2 w1 = __builtin_bit_cast(s16x2, w.x), w2 = __builtin_bit_cast(s16x2, w.y);
+        // gfx950's dot2 accumulates in place (v_dot2c_i32_i16): one chain per component, a . w + b . (-w); negating the
+        // twiddle is exact (|w| <= 2^14), negating a sample would not be (-32768)
+        const s16x2 zero2 = {0, 0};
+        const int pr = __builtin_amdgcn_sdot2(av, w1, __builtin_amdgcn_sdot2(bv, zero2 - w1, 0, false), false);
+        const int pi = __builtin_amdgcn_sdot2(av, w2, __builtin_amdgcn_sdot2(bv, zero2 - w2, 0, false), false);
+        int qr, qi;
         if constexpr (CONV) {
-          xr[ia] = wrap16(trim_conv<1>(sr));
-          xi[ia] = wrap16(trim_conv<1>(si));
-          xr[ib] = wrap16(trim_conv<15>(pr));
-          xi[ib] = wrap16(trim_conv<15>(pi));
+          qr = trim_conv<15>(pr);
+          qi = trim_conv<15>(pi);
         } else {
-          xr[ia] = wrap16(trim_n(sr, 1, rg.trim_bias1, 0));
-          xi[ia] = wrap16(trim_n(si, 1, rg.trim_bias1, 0));
-          xr[ib] = wrap16(trim_n(pr, 15, rg.trim_bias15, 0));
-          xi[ib] = wrap16(trim_n(pi, 15, rg.trim_bias15, 0));
+          qr = trim_n(pr, 15, rg.trim_bias15, 0);
+          qi = trim_n(pi, 15, rg.trim_bias15, 0);
         }
+        z[ib] = __builtin_amdgcn_perm((uint32_t)qr, (uint32_t)qi, 0x05040100u);  // {qr[15:0], qi[15:0]}
       }
     }
   }
@@ -464,7 +489,7 @@ __device__ __forceinline__ int wrap_bits(long long x, int bits) {
 }
 
 template <int M, int P>
-__device__ __forceinline__ void pass_fx_opt(int (&xr)[16], int (&xi)[16], int tau, const uint32_t* tw,
+__device__ __forceinline__ void pass_fx_opt(int (&xr)[16], int (&xi)[16], int tau, const uint2* tw,
                                             const ChainRegs& rg) {
   constexpr int W = plan_w(M, P), LO = plan_lo(M, P), G = 16 >> W, T = threads_per_frame(M);
 #pragma unroll
@@ -478,14 +503,14 @@ __device__ __forceinline__ void pass_fx_opt(int (&xr)[16], int (&xi)[16], int ta
       const int lsb = !grow && ((rg.keep_lsb_mask >> s) & 1u);
       const int sh_sum = (grow || lsb) ? 0 : 1, sh_prod = 14 + sh_sum;
       const int wout = 16 + __popc(rg.expand_mask & ((2u << s) - 1u));
-      const uint32_t* tws = tw + (low << s);
+      const uint2* tws = tw + (low << s);
 #pragma unroll
       for (int r0 = 0; r0 < (1 << W); ++r0) {
         if (r0 & (1 << bl)) continue;
         const int r1 = r0 | (1 << bl);
         const int jj = r0 & ((1 << bl) - 1);
-        const uint32_t w = tws[(jj << LO) << s];
-        const long long wr = (short)(w >> 16), wi = (short)(w & 0xffffu);
+        const uint2 w = tws[(jj << LO) << s];
+        const long long wr = fx_rom_wr(w), wi = fx_rom_wi(w);
         const int ia = g * (1 << W) + r0, ib = g * (1 << W) + r1;
         const long long sr = (long long)xr[ia] + xr[ib], si = (long long)xi[ia] + xi[ib];
         const long long dr = (long long)xr[ia] - xr[ib], di = (long long)xi[ia] - xi[ib];
@@ -508,12 +533,15 @@ __device__ __forceinline__ void pass_fx_opt(int (&xr)[16], int (&xi)[16], int ta
 // (the stage-option path: 180 VGPRs against 77-140 for the others), i.e. half the occupancy for every configuration.
 template <int M, int FX = -1>
 __device__ __forceinline__ void fft_fx_frame(int (&xr)[16], int (&xi)[16], int tau, unsigned char* fbase,
-                                             const uint32_t* rom, const ChainRegs& rg) {
+                                             const uint2* rom, const ChainRegs& rg) {
   constexpr int NP = plan_np(M);
   uint32_t* buf = reinterpret_cast<uint32_t*>(fbase);
   auto run = [&](auto conv_c) {
     constexpr bool CONV = decltype(conv_c)::value;
-    pass_fx<M, 0, CONV>(xr, xi, tau, rom, rg);
+    uint32_t z[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) z[e] = ((uint32_t)xr[e] << 16) | ((uint32_t)xi[e] & 0xffffu);  // folds away behind a beat's unpacking
+    pass_fx_pk<M, 0, CONV>(z, tau, rom, rg);
     auto exchange = [&](auto pc) {
       constexpr int P = decltype(pc)::value;
       constexpr int W0 = plan_w(M, P - 1), LO0 = plan_lo(M, P - 1);
@@ -523,27 +551,25 @@ __device__ __forceinline__ void fft_fx_frame(int (&xr)[16], int (&xi)[16], int t
       for (int g = 0; g < (16 >> W0); ++g) {
         uint32_t* b0 = buf + slot_base<M, LO0, W0, LAST>(tau, g);
 #pragma unroll
-        for (int r = 0; r < (1 << W0); ++r) {
-          const int e = g * (1 << W0) + r;
-          b0[slot_delta<M, LO0, W0>(r)] = ((uint32_t)xr[e] << 16) | ((uint32_t)xi[e] & 0xffffu);
-        }
+        for (int r = 0; r < (1 << W0); ++r) b0[slot_delta<M, LO0, W0>(r)] = z[g * (1 << W0) + r];
       }
       __syncthreads();
 #pragma unroll
       for (int g = 0; g < (16 >> W1); ++g) {
         const uint32_t* b1 = buf + slot_base<M, LO1, W1, LAST>(tau, g);
 #pragma unroll
-        for (int r = 0; r < (1 << W1); ++r) {
-          const uint32_t b = b1[slot_delta<M, LO1, W1>(r)];
-          xr[g * (1 << W1) + r] = (int)(short)(b >> 16);
-          xi[g * (1 << W1) + r] = (int)(short)(b & 0xffffu);
-        }
+        for (int r = 0; r < (1 << W1); ++r) z[g * (1 << W1) + r] = b1[slot_delta<M, LO1, W1>(r)];
       }
-      pass_fx<M, P, CONV>(xr, xi, tau, rom, rg);
+      pass_fx_pk<M, P, CONV>(z, tau, rom, rg);
     };
     exchange(std::integral_constant<int, 1>{});
     if constexpr (NP > 2) exchange(std::integral_constant<int, 2>{});
     if constexpr (NP > 3) exchange(std::integral_constant<int, 3>{});
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      xr[e] = (int)(short)(z[e] >> 16);
+      xi[e] = (int)(short)(z[e] & 0xffffu);
+    }
   };
   // expandLogic / keepMSBorLSB = false somewhere: generic stages, 8-byte exchange slots (words grow past 16 bits)
   auto run_opt = [&]() {
@@ -647,9 +673,15 @@ struct CfarMath<int> {
   // Ranges: magnitudes are 16-bit, so cut / thr products below fit 32 bits; stat * scaler needs 64.
   static __device__ __forceinline__ uint32_t finish(int stat, int cut, bool group_ok, int k,
                                                     int log2n, const ChainRegs& rg) {
-    const long long prod = ((long long)stat * (long long)rg.scaler_raw) << rg.lin_shl;
-    const long long lin64 = prod >> rg.lin_shr;  // arithmetic: floor, as the spec's trim_shift
-    const int lin = lin64 > (long long)rg.tmax ? rg.tmax : (lin64 < (long long)rg.tmin ? rg.tmin : (int)lin64);
+    int lin;
+    if (rg.fast32) {  // (uniform) the product is exact in 32 bits: the same integers as the 64-bit form below
+      const int l32 = (__mul24(stat, (int)rg.scaler_raw) << rg.lin_shl) >> rg.lin_shr;  // arithmetic: floor, as the spec's trim_shift
+      lin = min(max(l32, rg.tmin), rg.tmax);
+    } else {
+      const long long prod = ((long long)stat * (long long)rg.scaler_raw) << rg.lin_shl;
+      const long long lin64 = prod >> rg.lin_shr;
+      lin = lin64 > (long long)rg.tmax ? rg.tmax : (lin64 < (long long)rg.tmin ? rg.tmin : (int)lin64);
+    }
     int lg = ((stat << rg.log_shl) >> rg.log_shr) + rg.log_scaler;
     lg = min(max(lg, rg.tmin), rg.tmax);
     const int thr = rg.linear ? lin : lg;

@@ -255,7 +255,7 @@ range_fx_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uin
   const bool live = row < n_rows;
   if (zero_count && blockIdx.x == 0 && tid == 0) zero_count[0] = zero_count[1] = 0u;
   unsigned char* fbase = smem + (size_t)fl * fft_image_slots(M) * 4;
-  uint32_t* rom = reinterpret_cast<uint32_t*>(smem + (size_t)FPW * fft_image_slots(M) * 4);
+  uint2* rom = reinterpret_cast<uint2*>(smem + (((size_t)FPW * fft_image_slots(M) * 4 + 7) & ~size_t(7)));
   const uint32_t* src = in + (size_t)(live ? row : 0) * N + first_sample<M>(tau);
   int xr[16], xi[16];
 #pragma unroll
@@ -273,7 +273,7 @@ range_fx_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uin
       xi[e] = (int)(short)((xi[e] * wq + (1 << 14)) >> 15);
     }
   }
-  for (int i = tid; i < N / 2; i += wg_size(M)) rom[i] = twq[i];
+  for (int i = tid; i < N / 2; i += wg_size(M)) rom[i] = fx_rom_entry(twq[i]);
   __syncthreads();
   fft_fx_frame<M>(xr, xi, tau, fbase, rom, rg);
   constexpr int NP = plan_np(M), WL = plan_w(M, NP - 1);
@@ -305,7 +305,7 @@ doppler_fx_kernel(const uint32_t* __restrict__ in, int32_t* __restrict__ mag, ui
   const uint32_t groups_per_ch = nr / C;
   const uint32_t ch = blockIdx.x / groups_per_ch, r0 = (blockIdx.x % groups_per_ch) * C;
   unsigned char* fbase = smem + (size_t)fl * kFxColBytes(MD);
-  uint32_t* rom = reinterpret_cast<uint32_t*>(smem + (size_t)C * kFxColBytes(MD));
+  uint2* rom = reinterpret_cast<uint2*>(smem + (((size_t)C * kFxColBytes(MD) + 7) & ~size_t(7)));
   const size_t col = (size_t)ch * ND * nr + map_index(0, r0 + fl, ND, nr, tile);
   const uint32_t pitch = tile ? kTileCols : nr;
   const uint32_t* src = in + col + (size_t)first_sample<MD>(tau) * pitch;
@@ -325,7 +325,7 @@ doppler_fx_kernel(const uint32_t* __restrict__ in, int32_t* __restrict__ mag, ui
       xi[e] = (int)(short)((xi[e] * wq + (1 << 14)) >> 15);
     }
   }
-  for (int i = tid; i < ND / 2; i += T * C) rom[i] = twq[i];
+  for (int i = tid; i < ND / 2; i += T * C) rom[i] = fx_rom_entry(twq[i]);
   __syncthreads();
   fft_fx_frame<MD>(xr, xi, tau, fbase, rom, rg);
   constexpr int NP = plan_np(MD), WL = plan_w(MD, NP - 1);
@@ -921,7 +921,7 @@ template <int M>
 static hipError_t launch_range_fx(const uint32_t* in, uint32_t* out, uint32_t n_rows, uint32_t nd, uint32_t tile,
                                   const uint32_t* twq, const ChainRegs& rg, uint32_t* zero_count, hipStream_t s, int device) {
   constexpr int fpw = frames_per_wg(M);
-  const size_t lds = (size_t)fpw * fft_image_slots(M) * 4 + ((size_t)1 << M) / 2 * 4;
+  const size_t lds = (((size_t)fpw * fft_image_slots(M) * 4 + 7) & ~size_t(7)) + ((size_t)1 << M) / 2 * 8;
   auto k = range_fx_kernel<M>;
   static LdsGrant granted;
   hipError_t e = grant_lds(k, lds, device, granted);
@@ -933,7 +933,7 @@ template <int MD>
 static hipError_t launch_doppler_fx(const uint32_t* in, int32_t* mag, uint32_t n_ch, uint32_t nr, uint32_t tile,
                                     const uint32_t* twq, const int16_t* win, const int16_t* log_lut, const ChainRegs& rg,
                                     hipStream_t s, int device) {
-  const size_t lds = (size_t)kFxColBytes(MD) * kFxCols + ((size_t)1 << MD) / 2 * 4;
+  const size_t lds = (((size_t)kFxColBytes(MD) * kFxCols + 7) & ~size_t(7)) + ((size_t)1 << MD) / 2 * 8;
   auto k = doppler_fx_kernel<MD>;
   static LdsGrant granted;
   hipError_t e = grant_lds(k, lds, device, granted);

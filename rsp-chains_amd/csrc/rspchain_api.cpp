@@ -317,6 +317,13 @@ rsp::ChainRegs snapshot(const rsp_chain* c) {
     r.log_scaler = ls >= 0 ? (int32_t)(r.scaler_raw >> ls) : (int32_t)(r.scaler_raw << -ls);
     r.tmax = (1 << (r.w_thr - 1)) - 1;
     r.tmin = -(1 << (r.w_thr - 1));
+    // bound of |statistic|: magnitudes are <= 32767 (linear modes) or 16 << binPointLog (log2 mode); a side sum holds
+    // R of them before divSum (the 2-D chain sums its whole training region: bounded by the same product of its sizes)
+    const int64_t mag_max = std::max<int64_t>(32767, int64_t(16) << r.bp_log);
+    int64_t cells = r.algorithm == 1 ? 1 : r.R;
+    if (p.dopplerPoints) cells = int64_t(2 * (r.R + r.G) + 1) * (2 * (p.refDoppler + p.guardDoppler) + 1);
+    const int64_t smax = ((cells * mag_max) >> r.div_sum) + 1;
+    r.fast32 = smax < (int64_t(1) << 23) && ((smax * int64_t(r.scaler_raw)) << r.lin_shl) < (int64_t(1) << 31) ? 1 : 0;
   }
   return r;
 }
