@@ -31,9 +31,10 @@ synchronize on both sides and reduced with MAX over ranks.  `value` = the MEDIAN
 the fastest; `blocks_ms` lists all five and `sclk_mhz` the shader clock the driver reported before / after each
 (sysfs pp_dpm_sclk), so that a slow block is attributable.  `roofline` is for the dominant kernel: algorithmic bytes
  / its mean launch duration measured with one HIP event pair per launch on the stream the kernel runs on
-(rsp_chain_profile_*) over a repeat of one block -- the event records perturb the stream by ~1 us per step, so
-they are kept out of the blocks `value` comes from; an event pair brackets dispatch + kernel, ~1-2 us more than the
-kernel's own begin / end timestamps that rocprofv3 reports (profiles/).
+(rsp_chain_profile_*) over a repeat of one block, outside the blocks `value` comes from.  For the 1-D chain the pair
+is bound to the kernel's dispatch (hipExtLaunchKernelGGL: the kernel's own begin / end timestamps, the quantity
+rocprofv3's kernel trace reports in profiles/); the 2-D chain's pair brackets its three kernels and their two
+boundaries.
 Prints ONE JSON line (rank 0).
 """
 from __future__ import annotations

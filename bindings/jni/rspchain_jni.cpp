@@ -43,5 +43,20 @@ JNIEXPORT void JNICALL Java_rspChain_RspChainNative_process(JNIEnv* env, jclass,
   else if (rc != RSP_OK) env->ThrowNew(env->FindClass("java/lang/RuntimeException"), rsp_last_error());
 }
 
+// Stream buffers in pinned host memory (rsp_host_alloc): rsp_chain_process DMAs them in place, at the PCIe link's
+// rate; a plain ByteBuffer.allocateDirect is pageable and goes through the library's pinned staging ring instead.
+JNIEXPORT jobject JNICALL Java_rspChain_RspChainNative_allocPinned(JNIEnv* env, jclass, jint device, jlong bytes) {
+  void* p = nullptr;
+  if (rsp_host_alloc((int)device, &p, (size_t)bytes) != RSP_OK) {
+    env->ThrowNew(env->FindClass("java/lang/OutOfMemoryError"), rsp_last_error());
+    return nullptr;
+  }
+  return env->NewDirectByteBuffer(p, bytes);
+}
+
+JNIEXPORT void JNICALL Java_rspChain_RspChainNative_freePinned(JNIEnv* env, jclass, jobject buf) {
+  (void)rsp_host_free(env->GetDirectBufferAddress(buf));
+}
+
 }  // extern "C"
 #endif

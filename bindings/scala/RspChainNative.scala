@@ -16,6 +16,9 @@ object RspChainNative {
   @native def destroy(handle: Long): Unit
   @native def memWriteWord(handle: Long, addr: Int, value: Int): Unit
   @native def process(handle: Long, in: ByteBuffer, nFrames: Long, out: ByteBuffer): Unit
+  /** direct ByteBuffer over pinned host memory (rsp_host_alloc): process() then moves it over PCIe in place */
+  @native def allocPinned(device: Int, bytes: Long): ByteBuffer
+  @native def freePinned(buf: ByteBuffer): Unit
 
   private def bp(t: FixedPoint): Int = t.binaryPoint.get
   private def w(t: FixedPoint): Int = t.getWidth
@@ -24,7 +27,7 @@ object RspChainNative {
   def marshal(p: FftMagCfarVanillaParameters, dtype: Int = 0, device: Int = 0): ByteBuffer = {
     val b = ByteBuffer.allocateDirect(512).order(ByteOrder.LITTLE_ENDIAN)
     val f = p.fftParams
-    Seq(16, 16, f.numPoints, if (f.useBitReverse) 1 else 0, if (f.runTime) 1 else 0, f.numAddPipes, f.numMulPipes).foreach(b.putInt)
+    Seq(w(f.protoIQ.real.asInstanceOf[FixedPoint]), w(f.protoTwiddle.real.asInstanceOf[FixedPoint]), f.numPoints, if (f.useBitReverse) 1 else 0, if (f.runTime) 1 else 0, f.numAddPipes, f.numMulPipes).foreach(b.putInt)
     (0 until 16).foreach(i => b.putInt(if (i < f.expandLogic.length) f.expandLogic(i) else 0))
     (0 until 16).foreach(i => b.putInt(if (i < f.keepMSBorLSB.length && !f.keepMSBorLSB(i)) 0 else 1))
     b.putInt(f.minSRAMdepth); b.putInt(bp(f.protoIQ.real.asInstanceOf[FixedPoint])); b.putInt(2 /* Convergent */)
@@ -52,13 +55,15 @@ class GpuFftMagCfarChain(params: FftMagCfarVanillaParameters) {
   /** axi4StreamIn: Seq[Int] as produced by RspChainTesterUtils.formAXI4StreamComplexData */
   def stream(axi4StreamIn: Seq[Int], fftSize: Int): Seq[Int] = {
     require(axi4StreamIn.length % fftSize == 0)
-    val in = ByteBuffer.allocateDirect(4 * axi4StreamIn.length).order(ByteOrder.LITTLE_ENDIAN)
+    val in = RspChainNative.allocPinned(0, 4L * axi4StreamIn.length).order(ByteOrder.LITTLE_ENDIAN)
     axi4StreamIn.foreach(in.putInt)
     // CFARParams.sendCut = true widens the output beat to 64 bits: two words per cell, {word, cut} (include/rspchain.h)
     val wordsPerCell = if (params.cfarParams.sendCut) 2 else 1
-    val out = ByteBuffer.allocateDirect(4 * wordsPerCell * axi4StreamIn.length).order(ByteOrder.LITTLE_ENDIAN)
+    val out = RspChainNative.allocPinned(0, 4L * wordsPerCell * axi4StreamIn.length).order(ByteOrder.LITTLE_ENDIAN)
     RspChainNative.process(h, in, axi4StreamIn.length / fftSize, out)
-    Seq.tabulate(wordsPerCell * axi4StreamIn.length)(i => out.getInt(4 * i))
+    val words = Seq.tabulate(wordsPerCell * axi4StreamIn.length)(i => out.getInt(4 * i))
+    RspChainNative.freePinned(in); RspChainNative.freePinned(out)
+    words
   }
   def close(): Unit = RspChainNative.destroy(h)
 }

@@ -235,9 +235,11 @@ int rsp_chain_synchronize(rsp_chain* c);
 /* hipEvent pair on the chain's stream around whatever is enqueued between the calls. */
 int rsp_chain_timer_start(rsp_chain* c);
 int rsp_chain_timer_stop(rsp_chain* c, float* elapsed_ms); /* synchronises */
-/* Per-launch timing of the dominant (chain) kernel alone: while enabled, every data-plane
- * call brackets that kernel with a HIP event pair on the chain's stream; _read
- * synchronises, returns the summed durations and the number of launches, and resets. */
+/* Per-launch timing of the dominant (chain) kernel alone: while enabled, every data-plane call of the 1-D chain binds
+ * a HIP event pair to the kernel's dispatch (hipExtLaunchKernelGGL: the kernel's own begin / end timestamps -- what
+ * rocprofv3's kernel trace reports; an event pair recorded around the launch would add the ~2 us of the dispatch);
+ * the 2-D chain brackets its three kernels with one recorded pair.  _read synchronises, returns the summed durations
+ * and the number of launches, and resets. */
 int rsp_chain_profile_enable(rsp_chain* c, int on);
 int rsp_chain_profile_read(rsp_chain* c, float* total_ms, uint32_t* launches);
 int rsp_device_count(int* n);

@@ -92,6 +92,40 @@ __device__ __forceinline__ V seg_scan(V v) {
 // every thread has passed the first barrier below.  Barriers are the hook policy's (Hooks::barrier(): __syncthreads()
 // in the plain kernels; the pipelined kernel of chain1d_pipe.hip keeps LDS-DMA loads in flight across the tail and
 // brings a barrier without a vector-memory wait).
+// the four scans of a thread (its quads e = 0..3) step by step SIDE BY SIDE: a DPP read needs two wait states behind
+// the VALU write of its source, and four independent chains cover them for each other -- one chain after the other
+// (seg_scan per quad) had an s_nop behind nearly every one of its 24 DPP adds
+template <int WD, typename V>
+__device__ __forceinline__ void seg_scan_x4(V (&v)[4]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] += dpp_v<0x111, 0xf, true>(v[e]);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] += dpp_v<0x112, 0xf, true>(v[e]);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] += dpp_v<0x114, 0xf, true>(v[e]);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] += dpp_v<0x118, 0xf, true>(v[e]);
+  if constexpr (std::is_same<V, float>::value) {
+    if constexpr (WD >= 32)
+      asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa\n\tv_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa\n\t"
+                   "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa\n\tv_add_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa"
+                   : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+    if constexpr (WD >= 64)
+      asm volatile("s_nop 0\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc\n\tv_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc\n\t"
+                   "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc\n\tv_add_f32_dpp %3, %3, %3 row_bcast:31 row_mask:0xc"
+                   : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+  } else {
+    if constexpr (WD >= 32)
+      asm volatile("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa\n\tv_add_u32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa\n\t"
+                   "v_add_u32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa\n\tv_add_u32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa"
+                   : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+    if constexpr (WD >= 64)
+      asm volatile("s_nop 0\n\tv_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc\n\tv_add_u32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc\n\t"
+                   "v_add_u32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc\n\tv_add_u32_dpp %3, %3, %3 row_bcast:31 row_mask:0xc"
+                   : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+  }
+}
+
 // inclusive scan over aligned groups of 4 lanes (16 cells): row shifts by 1 and 2, kept out of the lanes whose source
 // sits in the neighbouring group
 __device__ __forceinline__ float seg4_scan(float v, unsigned tid) {
@@ -161,8 +195,13 @@ __device__ __forceinline__ void quad_tail(unsigned char* fbase, const V (&mg)[16
       p1[e] = mq[e][0];
       p2[e] = p1[e] + mq[e][1];
       p3[e] = p2[e] + mq[e][2];
-      if constexpr (SHORTW) inc[e] = seg4_scan(p3[e] + mq[e][3], threadIdx.x);
-      else inc[e] = seg_scan<WD, V>(p3[e] + mq[e][3]);
+      inc[e] = p3[e] + mq[e][3];
+    }
+    if constexpr (SHORTW) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) inc[e] = seg4_scan(inc[e], threadIdx.x);
+    } else {
+      seg_scan_x4<WD, V>(inc);
     }
     V tot[4];
 #pragma unroll

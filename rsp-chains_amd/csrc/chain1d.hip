@@ -1,6 +1,7 @@
 // Launchers of the fused 1-D chain kernels: FFT -> magnitude -> CFAR, one launch per batch of frames.
 // Kernels: chain_front.hpp (shared front end), cfar_quad.hpp / cfar_cell.hpp / cfar_gos.hpp (the tails).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "cfar_cell.hpp"
 #include "cfar_gos.hpp"
@@ -32,7 +33,7 @@ static hipError_t launch_gos(const Chain1dLaunch& a) {
   auto go = [&](auto k, LdsGrant& g) -> hipError_t {
     hipError_t err = grant_lds(k, lds, a.device, g);
     if (err != hipSuccess) return err;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(wg_size(M)), lds, a.stream, a.in, a.out, a.n_frames, a.regs, lay,
+    hipExtLaunchKernelGGL(k, dim3(grid), dim3(wg_size(M)), lds, a.stream, a.ev_start, a.ev_stop, 0, a.in, a.out, a.n_frames, a.regs, lay,
                        a.twiddles, a.log_lut, a.frame_count, a.frame_det);
     return hipGetLastError();
   };
@@ -66,7 +67,7 @@ static hipError_t launch_quad(const Chain1dLaunch& a) {
       auto k = chain1d_quad_kernel<M, kPartFixed, FX, SMALL, SHORTW>;
       hipError_t e = grant_lds(k, lds, a.device, granted);
       if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(k, dim3(grid), dim3(wg_size(M)), lds, a.stream, a.in, a.out, a.n_frames,
+      hipExtLaunchKernelGGL(k, dim3(grid), dim3(wg_size(M)), lds, a.stream, a.ev_start, a.ev_stop, 0, a.in, a.out, a.n_frames,
                          a.regs, a.twiddles, a.log_lut, a.frame_count, a.frame_det);
       return hipGetLastError();
     };
@@ -93,7 +94,7 @@ static hipError_t launch_m(const Chain1dLaunch& a) {
     auto k = chain1d_kernel<M, kPartFixed, FX>;
     hipError_t e = grant_lds(k, lds, a.device, granted);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(wg_size(M)), lds, a.stream, a.in, a.out, a.n_frames,
+    hipExtLaunchKernelGGL(k, dim3(grid), dim3(wg_size(M)), lds, a.stream, a.ev_start, a.ev_stop, 0, a.in, a.out, a.n_frames,
                        a.regs, a.twiddles, a.log_lut, a.frame_count, a.frame_det);
     return hipGetLastError();
   });

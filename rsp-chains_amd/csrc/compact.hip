@@ -35,6 +35,8 @@ hipError_t launch_chain1d(const Chain1dLaunch& a0) {
     a.out = a0.out ? a0.out + (((uint64_t)done << a0.log2n) << (a0.regs.send_cut ? 1 : 0)) : nullptr;
     a.frame_count = a0.frame_count ? a0.frame_count + done : nullptr;
     a.frame_det = a0.frame_det ? a0.frame_det + (uint64_t)done * kFrameDetCap : nullptr;
+    a.ev_start = done == 0 ? a0.ev_start : nullptr;                          // first piece starts the clock,
+    a.ev_stop = done + max_frames >= a0.n_frames ? a0.ev_stop : nullptr;     // the last one stops it
     hipError_t e = hipSuccess;
     // side libraries of tools/experiments/ (kept buildable so that recorded negative results can be re-measured)
     // define this symbol; the product library does not, and the branch is never taken

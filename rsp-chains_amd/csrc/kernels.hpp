@@ -27,6 +27,9 @@ struct Chain1dLaunch {
   uint32_t max_frames_per_launch;  // 0 = as many as 32-bit byte offsets allow; tests force the split path
   bool force_generic_tail;         // tests / A-B: per-cell CFAR tail even where the quad tail applies
   bool experiment;                 // RSP_OPT_EXPERIMENT: hand the launch to a side library's kernel (tools/experiments/)
+  // optional: events bound to the kernel DISPATCH (hipExtLaunchKernelGGL): its own begin / end timestamps, what
+  // rocprofv3's kernel trace reports -- an event pair recorded around the launch also times the dispatch (~2 us)
+  hipEvent_t ev_start, ev_stop;
 };
 
 hipError_t launch_chain1d(const Chain1dLaunch& a);

@@ -473,21 +473,18 @@ int launch_frames(rsp_chain* c, const void* d_in, size_t n_frames, uint32_t* d_o
     a.frame_count = c->d_fcount + slot0;
     a.frame_det = c->d_fdet + (size_t)slot0 * rsp::kFrameDetCap;
   }
-  hipEvent_t pe0 = nullptr, pe1 = nullptr;
-  if (c->profiling) {
+  if (c->profiling) {  // events bound to the kernel dispatch itself (begin / end of the kernel, as rocprofv3 reports it)
     if (c->prof_used == c->prof_events.size()) {
       hipEvent_t e0, e1;
       HIP_TRY(hipEventCreate(&e0));
       HIP_TRY(hipEventCreate(&e1));
       c->prof_events.emplace_back(e0, e1);
     }
-    pe0 = c->prof_events[c->prof_used].first;
-    pe1 = c->prof_events[c->prof_used].second;
+    a.ev_start = c->prof_events[c->prof_used].first;
+    a.ev_stop = c->prof_events[c->prof_used].second;
     ++c->prof_used;
-    HIP_TRY(hipEventRecord(pe0, c->stream));
   }
   HIP_TRY(rsp::launch_chain1d(a));
-  if (pe1) HIP_TRY(hipEventRecord(pe1, c->stream));
   return RSP_OK;
 }
 

@@ -6,6 +6,7 @@
 // kernels: radix-2 DIF stage by stage (FIXED16: Q2.14 twiddles, 1-bit / 15-bit trims), magnitude,
 // direct-sum CFAR windows (all of CA / GO / SO / CASH / GOS, grouping, log, zero or wrap edges).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <float.h>
 
 #include <type_traits>
@@ -236,13 +237,13 @@ hipError_t launch_chain1d_small(const Chain1dLaunch& a) {
     auto k = chain1d_small_kernel<true>;
     e = grant_lds(k, lds, a.device, granted[0]);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds, a.stream, a.in, a.out, a.n_frames, a.log2n, a.regs, a.twiddles,
+    hipExtLaunchKernelGGL(k, dim3(grid), dim3(64), lds, a.stream, a.ev_start, a.ev_stop, 0, a.in, a.out, a.n_frames, a.log2n, a.regs, a.twiddles,
                        a.log_lut, a.frame_count, a.frame_det);
   } else {
     auto k = chain1d_small_kernel<false>;
     e = grant_lds(k, lds, a.device, granted[1]);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds, a.stream, a.in, a.out, a.n_frames, a.log2n, a.regs, a.twiddles,
+    hipExtLaunchKernelGGL(k, dim3(grid), dim3(64), lds, a.stream, a.ev_start, a.ev_stop, 0, a.in, a.out, a.n_frames, a.log2n, a.regs, a.twiddles,
                        a.log_lut, a.frame_count, a.frame_det);
   }
   return hipGetLastError();
