@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define RSP_ABI_VERSION 2
+#define RSP_ABI_VERSION 3
 #define RSP_MAX_STAGES 16
 
 enum {

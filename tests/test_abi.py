@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(lib, n), f"{n} declared in rspchain.h but not exported by librspchain.so"
         assert n in N.SIGNATURES, f"{n} has no ctypes signature in _native.py"
     assert set(N.SIGNATURES) == set(names)
-    assert lib.rsp_abi_version() == 2
+    assert lib.rsp_abi_version() == 3   # v3: rsp_host_alloc / _free / _register / _unregister, RSP_OPT_EXPERIMENT / _HOST_CHUNK_BYTES
 
 
 def test_struct_layout_matches_header(tmp_path):

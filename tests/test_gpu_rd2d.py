@@ -381,3 +381,31 @@ def test_rd2d_fixed_walker_equals_tile_kernel(gpu, mode):
             dut.configure(rt)
             dut.set_option(dut.FORCE_TILED_CFAR2D, tiled)
             assert np.array_equal(dut.stream(beats), ref), tiled
+
+
+def test_rd2d_host_entry_chunked_by_channel(gpu):
+    """The host-buffer entry cuts a batch into pipeline chunks (H2D || kernels || D2H); the 2-D chain's unit is a
+    channel.  One channel per chunk, more chunks than staging slots, pageable and pinned buffers: the words of the
+    one-launch device call, and the detection call (chunked kernels + one dense compaction) its peaks."""
+    nr, nd, n_ch = 512, 256, 5
+    params = rd_params(nr, nd)
+    rt = R.RunTimeRspChainParams(fftSize=nr, CFARMode="Cell Averaging", refWindowSize=8, guardWindowSize=2, divSum=4,
+                                 thresholdScaler=2.0)
+    x, _ = targets(n_ch, nd, nr, seed=78)
+    with R.FftMagCfarChainVanilla(params) as dut:
+        dut.configure(rt)
+        d_in = R.DeviceBuffer(x.nbytes); d_in.upload(x)
+        d_out = R.DeviceBuffer(x.size * 4)
+        dut.process_device(d_in.ptr, n_ch, d_out.ptr)
+        dut.synchronize()
+        ref = d_out.download(np.uint32, x.size).reshape(n_ch, nd, nr)
+        dut.set_option(dut.HOST_CHUNK_BYTES, 1)                      # one channel (1 MiB) per chunk: 5 chunks, 3 slots
+        assert np.array_equal(dut.stream(x), ref)
+        hin, hout = R.HostBuffer(x.shape, np.complex64), R.HostBuffer(x.size, np.uint32)
+        hin.array[...] = x
+        assert np.array_equal(dut.stream(hin.array, out=hout.array), ref)
+        det, found = dut.detections(x)
+        ch, d, r = np.nonzero(ref & 1)
+        assert found == ch.size > 50
+        assert np.array_equal(det["frame"], ch) and np.array_equal(det["doppler"], d) and np.array_equal(det["bin"], r)
+        assert np.array_equal(det["word"], ref[ch, d, r])
