@@ -10,7 +10,7 @@
 // halo (zeros or the wrapped image).
 
 #pragma once
-#include "chain_front.hpp"
+#include "cfar_quad.hpp"
 
 namespace rsp {
 
@@ -128,15 +128,15 @@ __device__ __forceinline__ void gos_stage(const V* mag, V* o1, V* o2, int tau, i
   const int a0 = -(G + R) + run * tau;  // first window start of this thread
   typename WinVec<V, R>::type s;
 #pragma unroll
-  for (int i = 0; i < R; ++i) s[i] = mag[pad(a0 + i + kHalo)];
+  for (int i = 0; i < R; ++i) s[i] = mag[a0 + i];
   sort_window<V, R>(s);
   const bool two = idx_lagg != idx_lead;
   for (int st = 0; st < run; ++st) {
-    const int oi = pad(run * tau + st);
+    const int oi = run * tau + st;
     o1[oi] = s[idx_lagg];
     if (two) o2[oi] = s[idx_lead];
     if (st + 1 < run) {
-      const V old = mag[pad(a0 + st + kHalo)], nw = mag[pad(a0 + st + R + kHalo)];
+      const V old = mag[a0 + st], nw = mag[a0 + st + R];
       slide<V, R>(s, old, nw);
     }
   }
@@ -204,20 +204,20 @@ __device__ __forceinline__ void gos_stage_split(const V* mag, V* o1, V* o2, int 
   typename WinVec<V, ND>::type d;
   typename WinVec<V, NB>::type b;
 #pragma unroll
-  for (int i = 0; i < ND; ++i) d[i] = mag[pad(a0 + i + kHalo)];
+  for (int i = 0; i < ND; ++i) d[i] = mag[a0 + i];
 #pragma unroll
-  for (int i = 0; i < NB; ++i) b[i] = mag[pad(a0 + ND + i + kHalo)];
+  for (int i = 0; i < NB; ++i) b[i] = mag[a0 + ND + i];
   sort_window<V, ND>(d);
   sort_window<V, NB>(b);
   const bool two = idx_lagg != idx_lead;
   if constexpr (KC >= 0) {
     // the cell that leaves and the cell that enters are read ONE step ahead: the slide is a chain of asm statements
     // the scheduler cannot hoist a load over, so a read issued inside the step would expose its LDS latency 16 times
-    V old = mag[pad(a0 + kHalo)], nw = mag[pad(a0 + R + kHalo)];
+    V old = mag[a0], nw = mag[a0 + R];
 #pragma unroll 1
     for (int st = 0; st < RUN; ++st) {
-      const V old_n = mag[pad(a0 + st + 1 + kHalo)], nw_n = mag[pad(a0 + st + 1 + R + kHalo)];  // inside the 256-cell halo
-      o1[pad(RUN * tau + st)] = select_split_k<KC, NB, ND, V>(b, d);
+      const V old_n = mag[a0 + st + 1], nw_n = mag[a0 + st + 1 + R];  // inside the 256-cell halo
+      o1[RUN * tau + st] = select_split_k<KC, NB, ND, V>(b, d);
       if (st + 1 < RUN) slide<V, ND>(d, old, nw);
       old = old_n;
       nw = nw_n;
@@ -233,11 +233,11 @@ __device__ __forceinline__ void gos_stage_split(const V* mag, V* o1, V* o2, int 
     for (int i = 0; i < ND; ++i) seq[NB + i] = d[ND - 1 - i];
     int k1 = idx_lagg, k2 = idx_lead;
     asm volatile("" : "+s"(k1), "+s"(k2));  // keep the five side branches inside the loop (no 32-way unswitching)
-    const int oi = pad(RUN * tau + st);
+    const int oi = RUN * tau + st;
     o1[oi] = select_bitonic<R, V>(seq, k1);
     if (two) o2[oi] = select_bitonic<R, V>(seq, k2);
     if (st + 1 < RUN) {
-      const V old = mag[pad(a0 + st + kHalo)], nw = mag[pad(a0 + st + R + kHalo)];
+      const V old = mag[a0 + st], nw = mag[a0 + st + R];
       slide<V, ND>(d, old, nw);
     }
   }
@@ -270,22 +270,46 @@ chain1d_gos_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint
   front_end<M, FIXED, V, FX>(in, frame, live, tau, fbase, rg, tw, log_lut,
                              reinterpret_cast<uint2*>(smem + (size_t)lay.frame_bytes * FPW), mg, hk);
 
-  V* mag = reinterpret_cast<V*>(fbase);  // cell x in [-256, N + 256] at slot pad(x + 256)
+  // LDS images of the tail, all unpadded (a thread's run of window starts puts its lanes RUN = 17 words apart: odd,
+  // conflict-free; the cells are handled as quads of four, like the CA tail):
+  //   mag[x], x in [-256, N + 256]   magnitudes with zero / wrapped halos
+  //   o1[s'], o2[s']                 order statistics of the window that starts at cell s' - (G + R)
+  using V4 = typename Vec4<V>::type;
+  V* mag = reinterpret_cast<V*>(fbase) + kHalo;
   V* o1 = reinterpret_cast<V*>(fbase + lay.o1_off);
   V* o2 = reinterpret_cast<V*>(fbase + lay.o2_off);
   uint32_t* det_cnt = reinterpret_cast<uint32_t*>(fbase + lay.det_off);
   uint2* det_stage = reinterpret_cast<uint2*>(fbase + lay.det_off + 8);
   const bool wrap = rg.edge != 0;
   __syncthreads();  // every thread is done reading the FFT image this overlays
-  write_mag<M, V>(mag, kHalo, tau, mg, rg.rev_order != 0);
+  {  // magnitudes to LDS in natural bin order (as the quad tail): register (g, p) holds bin (bitrev(p) << (M - WL)) | (g T + tau)
+    constexpr int NP = plan_np(M), WL = plan_w(M, NP - 1);
+    if (rg.rev_order) {  // useBitReverse = false: bin b at stream position bitrev(b) = (bitrev(g T + tau) << WL) | p
+#pragma unroll
+      for (int g = 0; g < (16 >> WL); ++g) {
+        V* mb = mag + ((__brev((unsigned)(g * T + tau)) >> (32 - (M - WL))) << WL);
+#pragma unroll
+        for (int p = 0; p < (1 << WL); ++p) mb[p] = mg[g * (1 << WL) + p];
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < (16 >> WL); ++g) {
+        V* mb = mag + g * T + tau;
+#pragma unroll
+        for (int p = 0; p < (1 << WL); ++p) mb[bitrev_c(p, WL) << (M - WL)] = mg[g * (1 << WL) + p];
+      }
+    }
+  }
   if (tau == 0) *det_cnt = 0u;
   __syncthreads();
   for (int h = tau; h < 32; h += T) {  // halos: 32 runs of 16 cells, zeros or the wrapped image
     const int x0 = h < 16 ? -kHalo + 16 * h : N + 16 * (h - 16);
     const int src = h < 16 ? x0 + N : x0 - N;
+    const V4 z4 = {V(0), V(0), V(0), V(0)};
 #pragma unroll
-    for (int e = 0; e < 16; ++e) mag[pad(x0 + e + kHalo)] = wrap ? mag[pad(src + e + kHalo)] : V(0);
-    if (h == 31) mag[pad(N + kHalo + kHalo)] = wrap ? mag[pad(kHalo + kHalo)] : V(0);
+    for (int e = 0; e < 16; e += 4)
+      *reinterpret_cast<V4*>(mag + x0 + e) = wrap ? *reinterpret_cast<const V4*>(mag + src + e) : z4;
+    if (h == 31) mag[N + kHalo] = wrap ? mag[kHalo] : V(0);
   }
   __syncthreads();
   if (hk.off(1)) {  // (side builds) no order-statistic stage: what the rest of the kernel costs
@@ -310,29 +334,50 @@ chain1d_gos_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint
   }
   __syncthreads();
 
-  // cell k = tau + T j: lagging statistic = o1[k] (window start k - G - R), leading = o2[k + 2G + R + 1]
+  // Cells as quads: thread tau owns cells 4 (tau + T e) + i.  Lagging statistic of cell k = o1[k] (window start k - G - R):
+  // one aligned 16-byte read per quad; leading = o2[k + D], D = 2 G + R + 1 -- odd (R is a power of two >= 4), so the
+  // four values straddle two aligned quads: two reads and a (wave-uniform) choice of components.
   uint32_t word[16];
+  V4 cutq[4];
   {
-    constexpr int JS = T + T / 16;
-    const V* pl = o1 + pad(tau);
-    const V* pr = o2 + pad(tau + 2 * rg.G + rg.R + 1);
-    const V* pm = mag + pad(tau + kHalo);
-    const int dl = ((tau & 15) == 0) ? 2 : 1, dr = ((tau & 15) == 15) ? 2 : 1;
+    const int D = 2 * rg.G + rg.R + 1;
+    const int d_lo = D & ~3;          // aligned part of the offset
+    const bool d3 = (D & 3) == 3;     // D mod 4 is 1 or 3
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const V a = pl[JS * j], b = pr[JS * j];
-      V stat;
-      if (rg.cfar_mode == 0) stat = CfarMath<V>::half_sum(a, b);
-      else if (rg.cfar_mode == 1) stat = a > b ? a : b;
-      else stat = a < b ? a : b;
-      const V cut = pm[JS * j];
-      bool group_ok = true;
-      if (rg.peak_grouping) group_ok = cut > pm[JS * j - dl] && cut > pm[JS * j + dr];
-      word[j] = CfarMath<V>::finish(stat, cut, group_ok, tau + T * j, M, rg);
+    for (int e = 0; e < 4; ++e) {
+      const int k0 = 4 * (tau + T * e);
+      const V4 a4 = *reinterpret_cast<const V4*>(o1 + k0);
+      const V4 l0 = *reinterpret_cast<const V4*>(o2 + k0 + d_lo), l1 = *reinterpret_cast<const V4*>(o2 + k0 + d_lo + 4);
+      const V4 b4 = d3 ? V4{l0[3], l1[0], l1[1], l1[2]} : V4{l0[1], l0[2], l0[3], l1[0]};
+      const V4 cut = *reinterpret_cast<const V4*>(mag + k0);
+      cutq[e] = cut;
+      V nl = V(0), nr = V(0);
+      if (rg.peak_grouping) {
+        nl = mag[k0 - 1];
+        nr = mag[k0 + 4];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const V a = a4[i], b = b4[i];
+        V stat;
+        if (rg.cfar_mode == 0) stat = CfarMath<V>::half_sum(a, b);
+        else if (rg.cfar_mode == 1) stat = a > b ? a : b;
+        else stat = a < b ? a : b;
+        bool group_ok = true;
+        if (rg.peak_grouping) group_ok = cut[i] > (i == 0 ? nl : cut[i - 1]) && cut[i] > (i == 3 ? nr : cut[i + 1]);
+        word[4 * e + i] = CfarMath<V>::finish(stat, cut[i], group_ok, k0 + i, M, rg);
+      }
     }
   }
-  emit_words<M, V>(word, out, frame, live, tau, det_cnt, det_stage, fcount, fdet,
-                   rg.send_cut ? mag + pad(tau + kHalo) : nullptr, T + T / 16);
+  {
+    QuadWords ww;
+    QuadCuts<V4> cc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) ww.w[j] = word[j];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cc.q[e] = cutq[e];
+    quad_emit<M, V, V4, SideHooks>(ww, cc, tau, frame, live, rg, out, fcount, fdet, det_cnt, det_stage);
+  }
 }
 
 // GOS kernel LDS: magnitude with 256-cell halos + one or two order-statistic arrays + staging
@@ -341,8 +386,8 @@ static GosLayout gos_layout(const ChainRegs& rg) {
   constexpr int N = 1 << M, T = threads_per_frame(M);
   GosLayout l;
   l.run = (N + 2 * rg.G + rg.R + 1 + T - 1) / T;
-  const int mag_bytes = 4 * (pad_slots(N + 2 * kHalo) + 2);
-  const int o_bytes = 4 * (pad_slots(l.run * T) + 2);
+  const int mag_bytes = 4 * (N + 2 * kHalo + 4);           // cells -256 .. N + 256, 16-byte multiple
+  const int o_bytes = 4 * ((l.run * T + 8 + 3) & ~3);       // + 8: the second aligned quad of a leading read
   l.o1_off = mag_bytes;
   l.o2_off = rg.idx_lagg != rg.idx_lead ? l.o1_off + o_bytes : l.o1_off;
   l.det_off = (l.o2_off + o_bytes + 7) & ~7;

@@ -87,6 +87,75 @@ __device__ __forceinline__ V seg_scan(V v) {
   return v;
 }
 
+// Dense words of a thread's four quads (cells 4 tau + 4 T e + i) to HBM -- one 16-byte store per quad, 1 KiB per
+// wave-instruction; two with sendCut = true: 64-bit beats {word, cut} -- and the frame's detection slots: peaks are
+// staged in LDS (det_cnt / det_stage), then written to the per-frame global slots without global atomics.
+// Shared by the quad CFAR tail and the GOS kernel's tail.
+// (the words and cuts travel BY VALUE: handed over as references to the caller's arrays, the arrays were also written to
+// scratch memory -- dead stores the compiler did not remove)
+struct QuadWords {
+  uint32_t w[16];
+  __device__ __forceinline__ uint32_t operator[](int i) const { return w[i]; }
+};
+template <typename V4> struct QuadCuts {
+  V4 q[4];
+  __device__ __forceinline__ const V4& operator[](int i) const { return q[i]; }
+};
+template <int M, typename V, typename V4, typename Hooks>
+__device__ __forceinline__ void quad_emit(const QuadWords word, const QuadCuts<V4> cutq, int tau, uint32_t frame, bool live,
+                                          const ChainRegs& rg, uint32_t* __restrict__ out, uint32_t* __restrict__ fcount,
+                                          uint2* __restrict__ fdet, uint32_t* det_cnt, uint2* det_stage) {
+  constexpr int N = 1 << M, T = threads_per_frame(M);
+  // ---- dense words: one 16-byte store per quad (1 KiB per wave-instruction) ----
+  if (!Hooks::kSerialQuads && live && out && rg.send_cut) {  // sendCut = true: 64-bit beat {word, cut}, two 16-byte stores per quad
+    char* obase = reinterpret_cast<char*>(out) + ((size_t)frame * N + 4u * (size_t)tau) * 8u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const V c0 = cutq[e][0], c1 = cutq[e][1], c2 = cutq[e][2], c3 = cutq[e][3];
+      const u32x4 lo4 = {word[4 * e], bits_of(c0), word[4 * e + 1], bits_of(c1)};
+      const u32x4 hi4 = {word[4 * e + 2], bits_of(c2), word[4 * e + 3], bits_of(c3)};
+      *reinterpret_cast<u32x4*>(obase + (size_t)(32 * T * e)) = lo4;
+      *reinterpret_cast<u32x4*>(obase + (size_t)(32 * T * e) + 16) = hi4;
+    }
+  } else if (live && out) {
+    char* obase = reinterpret_cast<char*>(out);
+    const uint32_t ooff = (frame * (uint32_t)N + 4u * (uint32_t)tau) * 4u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const u32x4 w4 = {word[4 * e], word[4 * e + 1], word[4 * e + 2], word[4 * e + 3]};
+      *reinterpret_cast<u32x4*>(obase + (size_t)ooff + (size_t)(16 * T * e)) = w4;
+    }
+  }
+  if (!kCountPath && fcount) {
+    uint32_t any = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) any |= word[j];
+    if (any & 1u) {  // rare: ~1 peak per 1000 cells; kept compact (a loop, not 16 unrolled copies)
+      uint32_t hits = 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) hits |= (word[j] & 1u) << j;
+      while (hits) {
+        const int j = __ffs(hits) - 1;
+        hits &= hits - 1;
+        uint32_t w = word[0];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) w = (j == q) ? word[q] : w;
+        const uint32_t slot = atomicAdd(det_cnt, 1u);
+        if (slot < (uint32_t)kFrameDetCap)
+          det_stage[slot] = make_uint2((uint32_t)(4 * tau + 4 * T * (j >> 2) + (j & 3)), w);
+      }
+    }
+    // per-frame detection slots (no global atomics): count + first kFrameDetCap peaks
+    Hooks::barrier();
+    if (live) {
+      const uint32_t cnt = *det_cnt;
+      if (tau == 0) fcount[frame] = cnt;
+      for (uint32_t i = tau; i < min(cnt, (uint32_t)kFrameDetCap); i += T)
+        fdet[(size_t)frame * kFrameDetCap + i] = det_stage[i];
+    }
+  }
+}
+
 // The tail proper: mg[] (front_end's register order) -> magnitude image -> scan -> cells -> dense words to HBM
 // (+ per-frame detection slots).  `fbase` = the frame's LDS (QuadLds<M, SMALL>), free to be overwritten once
 // every thread has passed the first barrier below.  Barriers are the hook policy's (Hooks::barrier(): __syncthreads()
@@ -400,56 +469,17 @@ __device__ __forceinline__ void quad_tail(unsigned char* fbase, const V (&mg)[16
 
   hk.stamp(10);
   hk.before_stores();
-  // ---- dense words: one 16-byte store per quad (1 KiB per wave-instruction) ----
-  if (!Hooks::kSerialQuads && live && out && rg.send_cut) {  // sendCut = true: 64-bit beat {word, cut}, two 16-byte stores per quad
-    char* obase = reinterpret_cast<char*>(out) + ((size_t)frame * N + 4u * (size_t)tau) * 8u;
+  {
+    QuadWords ww;
+    QuadCuts<V4> cc;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const V c0 = mq[e][0], c1 = mq[e][1], c2 = mq[e][2], c3 = mq[e][3];
-      const u32x4 lo4 = {word[4 * e], bits_of(c0), word[4 * e + 1], bits_of(c1)};
-      const u32x4 hi4 = {word[4 * e + 2], bits_of(c2), word[4 * e + 3], bits_of(c3)};
-      *reinterpret_cast<u32x4*>(obase + (size_t)(32 * T * e)) = lo4;
-      *reinterpret_cast<u32x4*>(obase + (size_t)(32 * T * e) + 16) = hi4;
-    }
-  } else if (live && out) {
-    char* obase = reinterpret_cast<char*>(out);
-    const uint32_t ooff = (frame * (uint32_t)N + 4u * (uint32_t)tau) * 4u;
+    for (int j = 0; j < 16; ++j) ww.w[j] = word[j];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const u32x4 w4 = {word[4 * e], word[4 * e + 1], word[4 * e + 2], word[4 * e + 3]};
-      *reinterpret_cast<u32x4*>(obase + (size_t)ooff + (size_t)(16 * T * e)) = w4;
-    }
+    for (int e = 0; e < 4; ++e) cc.q[e] = mq[e];
+    quad_emit<M, V, V4, Hooks>(ww, cc, tau, frame, live, rg, out, fcount, fdet, det_cnt, det_stage);
   }
   hk.stamp(11);
   hk.report();
-  if (!kCountPath && fcount) {
-    uint32_t any = 0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) any |= word[j];
-    if (any & 1u) {  // rare: ~1 peak per 1000 cells; kept compact (a loop, not 16 unrolled copies)
-      uint32_t hits = 0;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) hits |= (word[j] & 1u) << j;
-      while (hits) {
-        const int j = __ffs(hits) - 1;
-        hits &= hits - 1;
-        uint32_t w = word[0];
-#pragma unroll
-        for (int q = 1; q < 16; ++q) w = (j == q) ? word[q] : w;
-        const uint32_t slot = atomicAdd(det_cnt, 1u);
-        if (slot < (uint32_t)kFrameDetCap)
-          det_stage[slot] = make_uint2((uint32_t)(4 * tau + 4 * T * (j >> 2) + (j & 3)), w);
-      }
-    }
-    // per-frame detection slots (no global atomics): count + first kFrameDetCap peaks
-    Hooks::barrier();
-    if (live) {
-      const uint32_t cnt = *det_cnt;
-      if (tau == 0) fcount[frame] = cnt;
-      for (uint32_t i = tau; i < min(cnt, (uint32_t)kFrameDetCap); i += T)
-        fdet[(size_t)frame * kFrameDetCap + i] = det_stage[i];
-    }
-  }
 }
 
 template <int M, bool FIXED, int FX, bool SMALL, bool SHORTW = false>
