@@ -48,11 +48,13 @@ template <> __device__ __forceinline__ float vmed3<float>(float a, float b, floa
 template <typename V, int R> struct WinVec { typedef V type __attribute__((ext_vector_type(R))); };
 
 // Batcher's odd-even merge sort, ascending: 191 compare-exchanges at R = 32 (bitonic: 240), 543 at R = 64 (672);
-// every index is a compile-time constant after unrolling
-template <typename V, int R>
-__device__ __forceinline__ void sort_window(typename WinVec<V, R>::type& s) {
+// every index is a compile-time constant after unrolling.  P0 > 1 runs only the merge phases p = P0, 2 P0, ...: it
+// MERGES s[0, P0) and s[P0, R), both sorted (P0 a power of two; the network for R elements is the one for the next
+// power of two without the comparators that touch an index >= R, whose inputs would be +infinity and stay put).
+template <typename V, int R, int P0 = 1, typename S>
+__device__ __forceinline__ void sort_net(S& s) {
 #pragma unroll
-  for (int p = 1; p < R; p <<= 1) {
+  for (int p = P0; p < R; p <<= 1) {
 #pragma unroll
     for (int k = p; k >= 1; k >>= 1) {
 #pragma unroll
@@ -69,6 +71,8 @@ __device__ __forceinline__ void sort_window(typename WinVec<V, R>::type& s) {
     }
   }
 }
+template <typename V, int R>
+__device__ __forceinline__ void sort_window(typename WinVec<V, R>::type& s) { sort_net<V, R>(s); }
 
 // lane mask of a < b into an SGPR pair / select by such a mask.  Inline asm: the compiler pairs every compare
 // with its select through VCC (one register: compare i+1 cannot start before select i has read it) and pads
@@ -91,8 +95,8 @@ __device__ __forceinline__ V select_mask(unsigned long long m, V if_set, V if_cl
 }
 
 // sorted s: remove one element equal to `old`, insert `nw`, stay sorted
-template <typename V, int R>
-__device__ __forceinline__ void slide(typename WinVec<V, R>::type& s, V old, V nw) {
+template <typename V, int R, typename S>
+__device__ __forceinline__ void slide_s(S& s, V old, V nw) {
   V t[R - 1];
 #pragma unroll
   for (int b0 = 0; b0 < R - 1; b0 += 8) {
@@ -114,6 +118,8 @@ __device__ __forceinline__ void slide(typename WinVec<V, R>::type& s, V old, V n
   for (int i = 1; i < R - 1; ++i) s[i] = vmed3(t[i - 1], nw, t[i]);
   s[R - 1] = vmax(t[R - 2], nw);
 }
+template <typename V, int R>
+__device__ __forceinline__ void slide(typename WinVec<V, R>::type& s, V old, V nw) { slide_s<V, R>(s, old, nw); }
 
 #ifndef RSP_GOS_SPLIT
 #define RSP_GOS_SPLIT 1
@@ -175,9 +181,10 @@ __device__ __forceinline__ V select_split_k(const VB& b, const VD& d) {
 #pragma unroll
   for (int i = ILO; i <= IHI; ++i) {
     const int j = K - 1 - i;
-    if (i < 0) t[i - ILO] = d[K];
-    else if (j < 0) t[i - ILO] = b[K];
-    else t[i - ILO] = vmax1<V>(b[i], d[j]);
+    // (indices clamped in the branches not taken: they are compile-time dead but still type-checked)
+    if (i < 0) t[i - ILO] = d[K < ND ? K : 0];
+    else if (j < 0) t[i - ILO] = b[K < NB ? K : 0];
+    else t[i - ILO] = vmax1<V>(b[i], d[j < 0 ? 0 : j]);
   }
 #pragma unroll
   for (int w = 1; w < NT; w <<= 1) {  // pairwise: a tree log2(NT) deep instead of a chain of NT dependent minima
@@ -239,6 +246,76 @@ __device__ __forceinline__ void gos_stage_split(const V* mag, V* o1, V* o2, int 
     if (st + 1 < RUN) {
       const V old = mag[a0 + st], nw = mag[a0 + st + R];
       slide<V, ND>(d, old, nw);
+    }
+  }
+}
+
+// R = 32, compile-time index: the thread's 17 window starts as TWO runs that share the sorted middle of their windows.
+// With m[j] = cell a0 + j: starts 0..7 all contain [7, 32), starts 8..16 all contain [16, 40); both contain C = [16, 32).
+//   sort C (16 cells) once; run A: common part = merge(C, sort [7, 16)) -- 25 cells --, sliding part 7 cells;
+//                           run B: common part = merge(C, sort [32, 40)) -- 24 cells --, sliding part 8 cells.
+// A slide costs 3 cells-in-the-sliding-part operations, so halving that part halves the dominant term: 15 slides of 19 /
+// 22 operations instead of 16 of 46; the sorts and merges cost 458 instead of 252.  ~1020 operations per 17 starts
+// against 1243 for one run of 17 (gos_stage_split).  Selection as there: select_split_k on the two sorted parts.
+template <typename V, int KC>
+__device__ __forceinline__ void gos_stage_split2(const V* mag, V* o1, int tau, int G) {
+  constexpr int R = 32, RUN = 17;
+  const V* m = mag + (-(G + R) + RUN * tau);  // m[j] = cell a0 + j, a0 the thread's first window start
+  V* o = o1 + RUN * tau;
+  V c[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) c[i] = m[16 + i];
+  sort_net<V, 16>(c);
+  {  // starts 0..7
+    V b[25], d[7];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) b[i] = c[i];
+    {
+      V e[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) e[i] = m[7 + i];
+      sort_net<V, 9>(e);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) b[16 + i] = e[i];
+    }
+    sort_net<V, 25, 16>(b);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) d[i] = m[i];
+    sort_net<V, 7>(d);
+    V old = m[0], nw = m[R];
+#pragma unroll 1
+    for (int st = 0; st < 8; ++st) {
+      const V old_n = m[st + 1], nw_n = m[st + 1 + R];  // one step ahead (see gos_stage_split)
+      o[st] = select_split_k<KC, 25, 7, V>(b, d);
+      if (st + 1 < 8) slide_s<V, 7>(d, old, nw);
+      old = old_n;
+      nw = nw_n;
+    }
+  }
+  {  // starts 8..16
+    V b[24], d[8];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) b[i] = c[i];
+    {
+      V f[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] = m[R + i];
+      sort_net<V, 8>(f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) b[16 + i] = f[i];
+    }
+    sort_net<V, 24, 16>(b);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d[i] = m[8 + i];
+    sort_net<V, 8>(d);
+    V old = m[8], nw = m[8 + R];
+#pragma unroll 1
+    for (int st = 8; st < RUN; ++st) {
+      const V old_n = m[st + 1], nw_n = m[st + 1 + R];  // inside the 256-cell halo
+      o[st] = select_split_k<KC, 24, 8, V>(b, d);
+      if (st + 1 < RUN) slide_s<V, 8>(d, old, nw);
+      old = old_n;
+      nw = nw_n;
     }
   }
 }
@@ -324,8 +401,8 @@ chain1d_gos_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint
       case 16: gos_stage<V, 16>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead); break;
       default:
         if (lay.run == 17 && RSP_GOS_SPLIT) {
-          if (rg.idx_lagg == rg.idx_lead && rg.idx_lagg == 24) gos_stage_split<V, 32, 17, 24>(mag, o1, o2, tau, rg.G, 24, 24);
-          else if (rg.idx_lagg == rg.idx_lead && rg.idx_lagg == 16) gos_stage_split<V, 32, 17, 16>(mag, o1, o2, tau, rg.G, 16, 16);
+          if (rg.idx_lagg == rg.idx_lead && rg.idx_lagg == 24) gos_stage_split2<V, 24>(mag, o1, tau, rg.G);
+          else if (rg.idx_lagg == rg.idx_lead && rg.idx_lagg == 16) gos_stage_split2<V, 16>(mag, o1, tau, rg.G);
           else gos_stage_split<V, 32, 17>(mag, o1, o2, tau, rg.G, rg.idx_lagg, rg.idx_lead);
         }
         else gos_stage<V, 32>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead);
