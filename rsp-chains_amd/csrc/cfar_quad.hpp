@@ -45,7 +45,7 @@ struct QuadLds {
   static constexpr int CFAR_BYTES = DET_OFF + 8 + 8 * kFrameDetCap;
   static constexpr int FFT_BYTES = 8 * fft_image_slots(M);
   static constexpr int BYTES = ((CFAR_BYTES > FFT_BYTES ? CFAR_BYTES : FFT_BYTES) + 15) & ~15;
-  static constexpr int ROM_BYTES = 8 * (N / 2);
+  static constexpr int ROM_BYTES = fx_rom_bytes(M);
 };
 
 // the geometry the quad tail is built for (host-side dispatch, launch_m)

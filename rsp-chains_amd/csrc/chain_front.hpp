@@ -46,7 +46,7 @@ struct FrameLds {
   static constexpr int CFAR_BYTES = DET_OFF + 8 + 8 * kFrameDetCap;
   static constexpr int FFT_BYTES = 8 * PADN;             // f32x2 per slot (FIXED16 uses 4 B)
   static constexpr int BYTES = ((CFAR_BYTES > FFT_BYTES ? CFAR_BYTES : FFT_BYTES) + 15) & ~15;
-  static constexpr int ROM_BYTES = 8 * (N / 2);  // FIXED16: LDS copy of the Q2.14 twiddle ROM ({W1, W2} per twiddle: fx_rom_entry), per workgroup
+  static constexpr int ROM_BYTES = fx_rom_bytes(M);  // FIXED16: LDS copy of the Q2.14 twiddle ROM ({W1, W2} per twiddle: fx_rom_entry), per workgroup
 };
 
 __device__ __forceinline__ int mag_slot(int x) { return pad(x + 16); }
@@ -172,10 +172,13 @@ __device__ __forceinline__ void front_end(const void* __restrict__ in, uint32_t 
       }
     }
     // twiddle ROM -> LDS once per workgroup (the sample loads above are already in flight)
-    for (int i = threadIdx.x; i < N / 2; i += wg_size(M)) rom[i] = fx_rom_entry(twq[i]);
+    fx_rom_fill(rom, twq, N / 2, threadIdx.x, wg_size(M));
     __syncthreads();
-    fft_fx_frame<M, FX>(xr, xi, tau, fbase, rom, rg);
-    if (rg.mag_mode == 2) {
+    fft_fx_frame<M, FX>(xr, xi, tau, fbase, rom, rg, hk);
+    if (hk.off(4)) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mg[e] = xr[e] & 32767;
+    } else if (rg.mag_mode == 2) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) mg[e] = jpl_fx(xr[e], xi[e]);
     } else {

@@ -421,8 +421,56 @@ __device__ __forceinline__ uint2 fx_rom_entry(uint32_t w) {  // w = (wr << 16) |
   const uint32_t wr = w >> 16, wi = w & 0xffffu;
   return make_uint2((wr << 16) | ((0u - wi) & 0xffffu), (wi << 16) | wr);
 }
+// LDS slot of twiddle k: one pad entry per 16 and one more per 256.  A stage's lookups differ between lanes by
+// low << s (low = the thread's low index bits): unpadded, the lanes of a wave then share 16 >> s bank pairs (s < 4) or
+// ONE (s >= 4) -- 68 % of the FIXED16 kernel's LDS cycles were bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
+// With the pads sixteen consecutive values of low land in sixteen different bank pairs for every s <= 7.  The slot is
+// additive over disjoint bit fields (no carries), so slot(low << s) + slot(constant part) is the address and the
+// constant part stays an instruction's immediate offset.
+__host__ __device__ constexpr int fx_rom_slot(int k) { return k + (k >> 4) + (k >> 8); }
+__host__ __device__ constexpr int fx_rom_slots(int M) { return fx_rom_slot((1 << M) / 2) + 1; }
+__host__ __device__ constexpr int fx_rom_bytes(int M) { return 8 * fx_rom_slots(M); }
+// global ROM (N/2 words) -> LDS, by all the workgroup's threads
+__device__ __forceinline__ void fx_rom_fill(uint2* rom, const uint32_t* __restrict__ twq, int half, int tid, int nthreads) {
+  for (int i = tid; i < half; i += nthreads) rom[fx_rom_slot(i)] = fx_rom_entry(twq[i]);
+}
 __device__ __forceinline__ int fx_rom_wr(uint2 e) { return (int)(short)(e.y & 0xffffu); }
 __device__ __forceinline__ int fx_rom_wi(uint2 e) { return (int)(short)(e.y >> 16); }
+
+// The butterfly's lower output for the twiddles W = 1 and W = -j (ROM entries 0 and N/4: {16384, 0} and {0, -16384},
+// exact in Q2.14): (a - b) 2^14 trimmed by 15 bits is (a - b) / 2 trimmed by one, so the product is the SUM's
+// arithmetic on a - b = a + ~b + 1, per 16-bit lane:
+//   floor((a - b) / 2) = (a & ~b) + ((a ^ ~b) >> 1) + ((a ^ ~b) & 1),  dropped bit = (a ^ b) & 1
+// 8 operations instead of 15 and no ROM read; 22 of the 32 butterflies of a 4-stage last pass (the last stage is all
+// W = 1, the one before it half 1 half -j, ...).  (a - b)(-j) = (a.im - b.im) + j (b.re - a.re) is the same on the
+// lane-swapped operands {a.im, b.re} - {b.im, a.re} (-x 2^14 trims like (b - a) 2^14: same integer).
+// The two 32-bit sums of a butterfly's product, pr = a . w1 - b . w1 + c and pi = a . w2 - b . w2 + c, as four
+// v_dot2_i32_i16 (VOP3P: the addend is an operand).  Through __builtin_amdgcn_sdot2 this compiler picks the
+// accumulate-in-place form (v_dot2c) and pays a v_mov 0 per chain; spelled here that is two operations less per
+// butterfly.  The compiler does not track dot-instruction hazards across inline asm, so the block keeps them itself:
+// the second dot of a chain reads the first's result as its addend (same opcode, SrcC: no wait states), and the
+// s_nop leaves the three wait states a dot result needs before any other VALU instruction may read it.
+__device__ __forceinline__ void fx_dot_pair(uint32_t a, uint32_t b, uint32_t w1, uint32_t w2, uint32_t n1, uint32_t n2,
+                                            int c, int& pr, int& pi) {
+  asm("v_dot2_i32_i16 %0, %3, %6, %8\n\t"
+      "v_dot2_i32_i16 %1, %3, %7, %8\n\t"
+      "v_dot2_i32_i16 %0, %2, %4, %0\n\t"
+      "v_dot2_i32_i16 %1, %2, %5, %1\n\t"
+      "s_nop 1"
+      : "=&v"(pr), "=&v"(pi)
+      : "v"(a), "v"(b), "v"(w1), "v"(w2), "v"(n1), "v"(n2), "s"(c));
+}
+
+template <bool CONV>
+__device__ __forceinline__ uint32_t fx_half_diff(uint32_t a, uint32_t b, uint32_t half_mask) {
+  const s16x2 one2 = {1, 1};
+  const uint32_t xn = ~(a ^ b);
+  const s16x2 f = __builtin_bit_cast(s16x2, a & ~b) + (__builtin_bit_cast(s16x2, xn) >> one2) +
+                  __builtin_bit_cast(s16x2, xn & 0x00010001u);
+  const uint32_t fb = __builtin_bit_cast(uint32_t, f);
+  const uint32_t rb = CONV ? (~xn & fb & 0x00010001u) : (~xn & half_mask);
+  return __builtin_bit_cast(uint32_t, f + __builtin_bit_cast(s16x2, rb));
+}
 
 template <int M, int P, bool CONV>
 __device__ __forceinline__ void pass_fx_pk(uint32_t (&z)[16], int tau, const uint2* tw, const ChainRegs& rg) {
@@ -437,13 +485,12 @@ __device__ __forceinline__ void pass_fx_pk(uint32_t (&z)[16], int tau, const uin
     for (int st = 0; st < W; ++st) {
       const int bl = W - 1 - st;
       const int s = M - 1 - (LO + bl);  // radix-2 stage number of this bit
-      const uint2* tws = tw + (low << s);
+      const uint2* tws = tw + fx_rom_slot(low << s);
 #pragma unroll
       for (int r0 = 0; r0 < (1 << W); ++r0) {
         if (r0 & (1 << bl)) continue;
         const int r1 = r0 | (1 << bl);
         const int jj = r0 & ((1 << bl) - 1);
-        const uint2 w = tws[(jj << LO) << s];
         const int ia = g * (1 << W) + r0, ib = g * (1 << W) + r1;
         const uint32_t a = z[ia], b = z[ib];
         const uint32_t x = a ^ b;
@@ -451,22 +498,35 @@ __device__ __forceinline__ void pass_fx_pk(uint32_t (&z)[16], int tau, const uin
         const uint32_t fb = __builtin_bit_cast(uint32_t, f);
         const uint32_t rb = CONV ? (x & fb & 0x00010001u) : (x & half_mask);  // convergent: a tie goes to the even neighbour
         z[ia] = __builtin_bit_cast(uint32_t, f + __builtin_bit_cast(s16x2, rb));
-        const s16x2 av = __builtin_bit_cast(s16x2, a), bv = __builtin_bit_cast(s16x2, b);
-        const s16x2 w1 = __builtin_bit_cast(s16x2, w.x), w2 = __builtin_bit_cast(s16x2, w.y);
-        // gfx950's dot2 accumulates in place (v_dot2c_i32_i16): one chain per component, a . w + b . (-w); negating the
-        // twiddle is exact (|w| <= 2^14), negating a sample would not be (-32768)
-        const s16x2 zero2 = {0, 0};
-        const int pr = __builtin_amdgcn_sdot2(av, w1, __builtin_amdgcn_sdot2(bv, zero2 - w1, 0, false), false);
-        const int pi = __builtin_amdgcn_sdot2(av, w2, __builtin_amdgcn_sdot2(bv, zero2 - w2, 0, false), false);
-        int qr, qi;
-        if constexpr (CONV) {
-          qr = trim_conv<15>(pr);
-          qi = trim_conv<15>(pi);
-        } else {
-          qr = trim_n(pr, 15, rg.trim_bias15, 0);
-          qi = trim_n(pi, 15, rg.trim_bias15, 0);
+        if (LO == 0 && jj == 0) {  // W = 1 (compile-time after unrolling: low = 0 in the pass of the last stages)
+          z[ib] = fx_half_diff<CONV>(a, b, half_mask);
+          continue;
         }
-        z[ib] = __builtin_amdgcn_perm((uint32_t)qr, (uint32_t)qi, 0x05040100u);  // {qr[15:0], qi[15:0]}
+        if (LO == 0 && (jj << s) == (1 << (M - 2))) {  // W = -j
+          z[ib] = fx_half_diff<CONV>(__builtin_amdgcn_alignbit(a, b, 16), __builtin_amdgcn_alignbit(b, a, 16), half_mask);
+          continue;
+        }
+        const uint2 w = tws[fx_rom_slot((jj << LO) << s)];
+        // a . w + b . (-w) per component (negating the twiddle is exact, |w| <= 2^14; negating a sample would not be),
+        // the trim's rounding constant as the first addend; the negations are shared by the butterflies of a twiddle
+        const s16x2 zero2 = {0, 0};
+        const uint32_t n1 = __builtin_bit_cast(uint32_t, zero2 - __builtin_bit_cast(s16x2, w.x));
+        const uint32_t n2 = __builtin_bit_cast(uint32_t, zero2 - __builtin_bit_cast(s16x2, w.y));
+        int pr, pi;
+        fx_dot_pair(a, b, w.x, w.y, n1, n2, CONV ? 16383 : rg.trim_bias15, pr, pi);
+        // the 16-bit results are bits [30:15] of the rounded sums = the high halves of twice them (mod 2^32: the
+        // wrap to 16 bits drops bit 31 anyway), so no shift right: one v_add_lshl per component, one v_perm for both.
+        // Convergent: (y + bit 15 of y) >> 15 with y = x + 2^14 - 1 (bit 15 of y and of x differ only where the
+        // increment cannot carry into bit 15).
+        uint32_t tr, ti;
+        if constexpr (CONV) {
+          tr = ((uint32_t)pr + __builtin_amdgcn_ubfe((uint32_t)pr, 15u, 1u)) << 1;
+          ti = ((uint32_t)pi + __builtin_amdgcn_ubfe((uint32_t)pi, 15u, 1u)) << 1;
+        } else {
+          tr = (uint32_t)pr << 1;
+          ti = (uint32_t)pi << 1;
+        }
+        z[ib] = __builtin_amdgcn_perm(tr, ti, 0x07060302u);  // {tr[31:16], ti[31:16]}
       }
     }
   }
@@ -503,13 +563,13 @@ __device__ __forceinline__ void pass_fx_opt(int (&xr)[16], int (&xi)[16], int ta
       const int lsb = !grow && ((rg.keep_lsb_mask >> s) & 1u);
       const int sh_sum = (grow || lsb) ? 0 : 1, sh_prod = 14 + sh_sum;
       const int wout = 16 + __popc(rg.expand_mask & ((2u << s) - 1u));
-      const uint2* tws = tw + (low << s);
+      const uint2* tws = tw + fx_rom_slot(low << s);
 #pragma unroll
       for (int r0 = 0; r0 < (1 << W); ++r0) {
         if (r0 & (1 << bl)) continue;
         const int r1 = r0 | (1 << bl);
         const int jj = r0 & ((1 << bl) - 1);
-        const uint2 w = tws[(jj << LO) << s];
+        const uint2 w = tws[fx_rom_slot((jj << LO) << s)];
         const long long wr = fx_rom_wr(w), wi = fx_rom_wi(w);
         const int ia = g * (1 << W) + r0, ib = g * (1 << W) + r1;
         const long long sr = (long long)xr[ia] + xr[ib], si = (long long)xi[ia] + xi[ib];
@@ -531,9 +591,9 @@ __device__ __forceinline__ void pass_fx_opt(int (&xr)[16], int (&xi)[16], int ta
 // FX selects the path at compile time -- 0: convergent trim (3-op closed form), 1: floor / half-up, 2: stage options;
 // -1: by the register snapshot at run time.  One kernel holding all three paths carries the registers of the widest
 // (the stage-option path: 180 VGPRs against 77-140 for the others), i.e. half the occupancy for every configuration.
-template <int M, int FX = -1>
+template <int M, int FX = -1, typename Hooks = NoHooks>
 __device__ __forceinline__ void fft_fx_frame(int (&xr)[16], int (&xi)[16], int tau, unsigned char* fbase,
-                                             const uint2* rom, const ChainRegs& rg) {
+                                             const uint2* rom, const ChainRegs& rg, Hooks hk = Hooks{}) {
   constexpr int NP = plan_np(M);
   uint32_t* buf = reinterpret_cast<uint32_t*>(fbase);
   auto run = [&](auto conv_c) {
@@ -541,12 +601,13 @@ __device__ __forceinline__ void fft_fx_frame(int (&xr)[16], int (&xi)[16], int t
     uint32_t z[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) z[e] = ((uint32_t)xr[e] << 16) | ((uint32_t)xi[e] & 0xffffu);  // folds away behind a beat's unpacking
-    pass_fx_pk<M, 0, CONV>(z, tau, rom, rg);
+    if (!hk.off(0)) pass_fx_pk<M, 0, CONV>(z, tau, rom, rg);
     auto exchange = [&](auto pc) {
       constexpr int P = decltype(pc)::value;
       constexpr int W0 = plan_w(M, P - 1), LO0 = plan_lo(M, P - 1);
       constexpr int W1 = plan_w(M, P), LO1 = plan_lo(M, P);
       constexpr bool LAST = P == NP - 1;
+      if (!hk.off(3)) {
 #pragma unroll
       for (int g = 0; g < (16 >> W0); ++g) {
         uint32_t* b0 = buf + slot_base<M, LO0, W0, LAST>(tau, g);
@@ -560,7 +621,8 @@ __device__ __forceinline__ void fft_fx_frame(int (&xr)[16], int (&xi)[16], int t
 #pragma unroll
         for (int r = 0; r < (1 << W1); ++r) z[g * (1 << W1) + r] = b1[slot_delta<M, LO1, W1>(r)];
       }
-      pass_fx_pk<M, P, CONV>(z, tau, rom, rg);
+      }
+      if (!hk.off(0)) pass_fx_pk<M, P, CONV>(z, tau, rom, rg);
     };
     exchange(std::integral_constant<int, 1>{});
     if constexpr (NP > 2) exchange(std::integral_constant<int, 2>{});

@@ -273,7 +273,7 @@ range_fx_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uin
       xi[e] = (int)(short)((xi[e] * wq + (1 << 14)) >> 15);
     }
   }
-  for (int i = tid; i < N / 2; i += wg_size(M)) rom[i] = fx_rom_entry(twq[i]);
+  fx_rom_fill(rom, twq, N / 2, tid, wg_size(M));
   __syncthreads();
   fft_fx_frame<M>(xr, xi, tau, fbase, rom, rg);
   constexpr int NP = plan_np(M), WL = plan_w(M, NP - 1);
@@ -325,7 +325,7 @@ doppler_fx_kernel(const uint32_t* __restrict__ in, int32_t* __restrict__ mag, ui
       xi[e] = (int)(short)((xi[e] * wq + (1 << 14)) >> 15);
     }
   }
-  for (int i = tid; i < ND / 2; i += T * C) rom[i] = fx_rom_entry(twq[i]);
+  fx_rom_fill(rom, twq, ND / 2, tid, T * C);
   __syncthreads();
   fft_fx_frame<MD>(xr, xi, tau, fbase, rom, rg);
   constexpr int NP = plan_np(MD), WL = plan_w(MD, NP - 1);
@@ -921,7 +921,7 @@ template <int M>
 static hipError_t launch_range_fx(const uint32_t* in, uint32_t* out, uint32_t n_rows, uint32_t nd, uint32_t tile,
                                   const uint32_t* twq, const ChainRegs& rg, uint32_t* zero_count, hipStream_t s, int device) {
   constexpr int fpw = frames_per_wg(M);
-  const size_t lds = (((size_t)fpw * fft_image_slots(M) * 4 + 7) & ~size_t(7)) + ((size_t)1 << M) / 2 * 8;
+  const size_t lds = (((size_t)fpw * fft_image_slots(M) * 4 + 7) & ~size_t(7)) + fx_rom_bytes(M);
   auto k = range_fx_kernel<M>;
   static LdsGrant granted;
   hipError_t e = grant_lds(k, lds, device, granted);
@@ -933,7 +933,7 @@ template <int MD>
 static hipError_t launch_doppler_fx(const uint32_t* in, int32_t* mag, uint32_t n_ch, uint32_t nr, uint32_t tile,
                                     const uint32_t* twq, const int16_t* win, const int16_t* log_lut, const ChainRegs& rg,
                                     hipStream_t s, int device) {
-  const size_t lds = (((size_t)kFxColBytes(MD) * kFxCols + 7) & ~size_t(7)) + ((size_t)1 << MD) / 2 * 8;
+  const size_t lds = (((size_t)kFxColBytes(MD) * kFxCols + 7) & ~size_t(7)) + fx_rom_bytes(MD);
   auto k = doppler_fx_kernel<MD>;
   static LdsGrant granted;
   hipError_t e = grant_lds(k, lds, device, granted);

@@ -7,7 +7,9 @@ R=$(cd "$(dirname "$0")/.." && pwd); C=$R/rsp-chains_amd/csrc; OUT=$1; shift
 T=$(mktemp -d /tmp/rspvar.XXXX)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function "$@" -c $C/chain1d.hip -o $T/chain1d.o &
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function "$@" -x hip -c $C/rspchain_api.cpp -o $T/rspchain_api.o &
+# the FIXED16 kernels of the default (convergent) trim too
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DRSP_PART_FX=0 "$@" -c $C/chain1d.hip -o $T/chain1d_fx0.o &
 wait
-OBJ=$(ls $C/build/*.o | grep -v -e '/chain1d.o' -e '/rspchain_api.o')
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/$OUT $T/chain1d.o $T/rspchain_api.o $OBJ
+OBJ=$(ls $C/build/*.o | grep -v -e '/chain1d.o' -e '/chain1d_fx0.o' -e '/rspchain_api.o')
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/$OUT $T/chain1d.o $T/chain1d_fx0.o $T/rspchain_api.o $OBJ
 rm -rf $T; echo built $OUT

@@ -58,6 +58,36 @@ __global__ void __launch_bounds__(1024) bench(unsigned long long* out, float* si
       REP8(asm volatile("ds_read_b32 %0, %8\n ds_read_b32 %1, %8 offset:1024\n ds_write_b32 %8, %2 offset:2048\n ds_read_b32 %3, %8 offset:3072\n"
                         "ds_read_b32 %4, %8 offset:4096\n ds_write_b32 %8, %5 offset:5120\n ds_read_b32 %6, %8 offset:6144\n ds_read_b32 %7, %8 offset:7168\n s_waitcnt lgkmcnt(0)"
                         : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"((unsigned)(threadIdx.x & 255) * 4u) : "memory");)
+    } else if constexpr (KIND == 12) {  // v_dot2_i32_i16 (VOP3P), 8 independent
+      REP8(asm volatile("v_dot2_i32_i16 %0, %0, %8, %9\n v_dot2_i32_i16 %1, %1, %8, %9\n v_dot2_i32_i16 %2, %2, %8, %9\n v_dot2_i32_i16 %3, %3, %8, %9\n v_dot2_i32_i16 %4, %4, %8, %9\n v_dot2_i32_i16 %5, %5, %8, %9\n v_dot2_i32_i16 %6, %6, %8, %9\n v_dot2_i32_i16 %7, %7, %8, %9"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x), "v"(c.x));)
+    } else if constexpr (KIND == 13) {  // v_dot2c_i32_i16 (accumulating; reads its own result as addend)
+      REP8(asm volatile("v_dot2c_i32_i16 %0, %0, %8\n v_dot2c_i32_i16 %1, %1, %8\n v_dot2c_i32_i16 %2, %2, %8\n v_dot2c_i32_i16 %3, %3, %8\n v_dot2c_i32_i16 %4, %4, %8\n v_dot2c_i32_i16 %5, %5, %8\n v_dot2c_i32_i16 %6, %6, %8\n v_dot2c_i32_i16 %7, %7, %8"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x));)
+    } else if constexpr (KIND == 14) {  // v_pk_add_u16
+      REP8(asm volatile("v_pk_add_u16 %0, %0, %8\n v_pk_add_u16 %1, %1, %8\n v_pk_add_u16 %2, %2, %8\n v_pk_add_u16 %3, %3, %8\n v_pk_add_u16 %4, %4, %8\n v_pk_add_u16 %5, %5, %8\n v_pk_add_u16 %6, %6, %8\n v_pk_add_u16 %7, %7, %8"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x));)
+    } else if constexpr (KIND == 15) {  // v_bfe_u32
+      REP8(asm volatile("v_bfe_u32 %0, %0, %8, %9\n v_bfe_u32 %1, %1, %8, %9\n v_bfe_u32 %2, %2, %8, %9\n v_bfe_u32 %3, %3, %8, %9\n v_bfe_u32 %4, %4, %8, %9\n v_bfe_u32 %5, %5, %8, %9\n v_bfe_u32 %6, %6, %8, %9\n v_bfe_u32 %7, %7, %8, %9"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x), "v"(c.x));)
+    } else if constexpr (KIND == 16) {  // v_perm_b32
+      REP8(asm volatile("v_perm_b32 %0, %0, %8, %9\n v_perm_b32 %1, %1, %8, %9\n v_perm_b32 %2, %2, %8, %9\n v_perm_b32 %3, %3, %8, %9\n v_perm_b32 %4, %4, %8, %9\n v_perm_b32 %5, %5, %8, %9\n v_perm_b32 %6, %6, %8, %9\n v_perm_b32 %7, %7, %8, %9"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x), "v"(c.x));)
+    } else if constexpr (KIND == 17) {  // v_add_lshl_u32
+      REP8(asm volatile("v_add_lshl_u32 %0, %0, %8, %9\n v_add_lshl_u32 %1, %1, %8, %9\n v_add_lshl_u32 %2, %2, %8, %9\n v_add_lshl_u32 %3, %3, %8, %9\n v_add_lshl_u32 %4, %4, %8, %9\n v_add_lshl_u32 %5, %5, %8, %9\n v_add_lshl_u32 %6, %6, %8, %9\n v_add_lshl_u32 %7, %7, %8, %9"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x), "v"(c.x));)
+    } else if constexpr (KIND == 18) {  // v_pk_ashrrev_i16
+      REP8(asm volatile("v_pk_ashrrev_i16 %0, %0, %8\n v_pk_ashrrev_i16 %1, %1, %8\n v_pk_ashrrev_i16 %2, %2, %8\n v_pk_ashrrev_i16 %3, %3, %8\n v_pk_ashrrev_i16 %4, %4, %8\n v_pk_ashrrev_i16 %5, %5, %8\n v_pk_ashrrev_i16 %6, %6, %8\n v_pk_ashrrev_i16 %7, %7, %8"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x));)
+    } else if constexpr (KIND == 19) {  // v_xor_b32
+      REP8(asm volatile("v_xor_b32 %0, %0, %8\n v_xor_b32 %1, %1, %8\n v_xor_b32 %2, %2, %8\n v_xor_b32 %3, %3, %8\n v_xor_b32 %4, %4, %8\n v_xor_b32 %5, %5, %8\n v_xor_b32 %6, %6, %8\n v_xor_b32 %7, %7, %8"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x));)
+    } else if constexpr (KIND == 20) {  // v_add3_u32
+      REP8(asm volatile("v_add3_u32 %0, %0, %8, %9\n v_add3_u32 %1, %1, %8, %9\n v_add3_u32 %2, %2, %8, %9\n v_add3_u32 %3, %3, %8, %9\n v_add3_u32 %4, %4, %8, %9\n v_add3_u32 %5, %5, %8, %9\n v_add3_u32 %6, %6, %8, %9\n v_add3_u32 %7, %7, %8, %9"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x), "v"(c.x));)
+    } else if constexpr (KIND == 21) {  // v_mad_i32_i24
+      REP8(asm volatile("v_mad_i32_i24 %0, %0, %8, %9\n v_mad_i32_i24 %1, %1, %8, %9\n v_mad_i32_i24 %2, %2, %8, %9\n v_mad_i32_i24 %3, %3, %8, %9\n v_mad_i32_i24 %4, %4, %8, %9\n v_mad_i32_i24 %5, %5, %8, %9\n v_mad_i32_i24 %6, %6, %8, %9\n v_mad_i32_i24 %7, %7, %8, %9"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x), "v"(c.x));)
     } else if constexpr (KIND == 5) {  // ds_write_b64, lane-contiguous
       REP8(asm volatile("ds_write_b64 %0, %1\n ds_write_b64 %0, %2 offset:2048\n ds_write_b64 %0, %3 offset:4096\n ds_write_b64 %0, %4 offset:6144\n"
                         "ds_write_b64 %0, %5 offset:8192\n ds_write_b64 %0, %6 offset:10240\n ds_write_b64 %0, %7 offset:12288\n ds_write_b64 %0, %8 offset:14336\n s_waitcnt lgkmcnt(0)"
@@ -103,5 +133,8 @@ int main() {
   run<4>("v_pk_mul_f32 op_sel", 64); run<5>("ds_write_b64 (8 + wait)", 64); run<6>("ds_read_b64 (8 + wait)", 64);
   run<7>("2 ds_write_b64 + 8 v_pk_fma", 80);
   run<8>("v_cmp->SGPR + v_cndmask (8 + 8)", 128); run<9>("v_med3_f32", 64); run<10>("v_min/v_max_f32", 64); run<11>("ds_read/write_b32 (6 + 2, wait)", 64);
+  run<12>("v_dot2_i32_i16", 64); run<13>("v_dot2c_i32_i16", 64); run<14>("v_pk_add_u16", 64); run<15>("v_bfe_u32", 64);
+  run<16>("v_perm_b32", 64); run<17>("v_add_lshl_u32", 64); run<18>("v_pk_ashrrev_i16", 64); run<19>("v_xor_b32", 64);
+  run<20>("v_add3_u32", 64); run<21>("v_mad_i32_i24", 64);
   return 0;
 }
