@@ -63,7 +63,7 @@ static hipError_t launch_quad(const Chain1dLaunch& a) {
     auto go = [&](auto small_c, auto short_c, LdsGrant& granted) -> hipError_t {
       constexpr bool SMALL = decltype(small_c)::value, SHORTW = decltype(short_c)::value;
       using L = QuadLds<M, SMALL, SHORTW>;
-      const size_t lds = L::BYTES * fpw + (kPartFixed ? L::ROM_BYTES : 0);
+      const size_t lds = kPartFixed ? (size_t)QuadFixedLds<M, SMALL, SHORTW, FX>::TOTAL : (size_t)L::BYTES * fpw;
       auto k = chain1d_quad_kernel<M, kPartFixed, FX, SMALL, SHORTW>;
       hipError_t e = grant_lds(k, lds, a.device, granted);
       if (e != hipSuccess) return e;

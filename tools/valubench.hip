@@ -88,6 +88,93 @@ __global__ void __launch_bounds__(1024) bench(unsigned long long* out, float* si
     } else if constexpr (KIND == 21) {  // v_mad_i32_i24
       REP8(asm volatile("v_mad_i32_i24 %0, %0, %8, %9\n v_mad_i32_i24 %1, %1, %8, %9\n v_mad_i32_i24 %2, %2, %8, %9\n v_mad_i32_i24 %3, %3, %8, %9\n v_mad_i32_i24 %4, %4, %8, %9\n v_mad_i32_i24 %5, %5, %8, %9\n v_mad_i32_i24 %6, %6, %8, %9\n v_mad_i32_i24 %7, %7, %8, %9"
                         : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x), "v"(c.x));)
+    } else if constexpr (KIND == 30) {  // v_add_u32_e32
+      REP8(asm volatile("v_add_u32_e32 %0, %0, %8\n v_add_u32_e32 %1, %1, %8\n v_add_u32_e32 %2, %2, %8\n v_add_u32_e32 %3, %3, %8\n v_add_u32_e32 %4, %4, %8\n v_add_u32_e32 %5, %5, %8\n v_add_u32_e32 %6, %6, %8\n v_add_u32_e32 %7, %7, %8"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x));)
+    } else if constexpr (KIND == 31) {  // v_sub_u32_e32
+      REP8(asm volatile("v_sub_u32_e32 %0, %0, %8\n v_sub_u32_e32 %1, %1, %8\n v_sub_u32_e32 %2, %2, %8\n v_sub_u32_e32 %3, %3, %8\n v_sub_u32_e32 %4, %4, %8\n v_sub_u32_e32 %5, %5, %8\n v_sub_u32_e32 %6, %6, %8\n v_sub_u32_e32 %7, %7, %8"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x));)
+    } else if constexpr (KIND == 32) {  // v_and_b32_e32
+      REP8(asm volatile("v_and_b32_e32 %0, %0, %8\n v_and_b32_e32 %1, %1, %8\n v_and_b32_e32 %2, %2, %8\n v_and_b32_e32 %3, %3, %8\n v_and_b32_e32 %4, %4, %8\n v_and_b32_e32 %5, %5, %8\n v_and_b32_e32 %6, %6, %8\n v_and_b32_e32 %7, %7, %8"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x));)
+    } else if constexpr (KIND == 33) {  // v_or_b32_e32
+      REP8(asm volatile("v_or_b32_e32 %0, %0, %8\n v_or_b32_e32 %1, %1, %8\n v_or_b32_e32 %2, %2, %8\n v_or_b32_e32 %3, %3, %8\n v_or_b32_e32 %4, %4, %8\n v_or_b32_e32 %5, %5, %8\n v_or_b32_e32 %6, %6, %8\n v_or_b32_e32 %7, %7, %8"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x));)
+    } else if constexpr (KIND == 34) {  // v_lshlrev_b32_e32
+      REP8(asm volatile("v_lshlrev_b32_e32 %0, %0, %8\n v_lshlrev_b32_e32 %1, %1, %8\n v_lshlrev_b32_e32 %2, %2, %8\n v_lshlrev_b32_e32 %3, %3, %8\n v_lshlrev_b32_e32 %4, %4, %8\n v_lshlrev_b32_e32 %5, %5, %8\n v_lshlrev_b32_e32 %6, %6, %8\n v_lshlrev_b32_e32 %7, %7, %8"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x));)
+    } else if constexpr (KIND == 35) {  // v_ashrrev_i32_e32
+      REP8(asm volatile("v_ashrrev_i32_e32 %0, %0, %8\n v_ashrrev_i32_e32 %1, %1, %8\n v_ashrrev_i32_e32 %2, %2, %8\n v_ashrrev_i32_e32 %3, %3, %8\n v_ashrrev_i32_e32 %4, %4, %8\n v_ashrrev_i32_e32 %5, %5, %8\n v_ashrrev_i32_e32 %6, %6, %8\n v_ashrrev_i32_e32 %7, %7, %8"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x));)
+    } else if constexpr (KIND == 36) {  // v_mul_f32_e32
+      REP8(asm volatile("v_mul_f32_e32 %0, %0, %8\n v_mul_f32_e32 %1, %1, %8\n v_mul_f32_e32 %2, %2, %8\n v_mul_f32_e32 %3, %3, %8\n v_mul_f32_e32 %4, %4, %8\n v_mul_f32_e32 %5, %5, %8\n v_mul_f32_e32 %6, %6, %8\n v_mul_f32_e32 %7, %7, %8"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x));)
+    } else if constexpr (KIND == 37) {  // v_mov_b32_e32
+      REP8(asm volatile("v_mov_b32_e32 %0, %0\n v_mov_b32_e32 %1, %1\n v_mov_b32_e32 %2, %2\n v_mov_b32_e32 %3, %3\n v_mov_b32_e32 %4, %4\n v_mov_b32_e32 %5, %5\n v_mov_b32_e32 %6, %6\n v_mov_b32_e32 %7, %7"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x));)
+    } else if constexpr (KIND == 38) {  // v_cndmask_b32_e32
+      REP8(asm volatile("v_cndmask_b32_e32 %0, %0, %8, vcc\n v_cndmask_b32_e32 %1, %1, %8, vcc\n v_cndmask_b32_e32 %2, %2, %8, vcc\n v_cndmask_b32_e32 %3, %3, %8, vcc\n v_cndmask_b32_e32 %4, %4, %8, vcc\n v_cndmask_b32_e32 %5, %5, %8, vcc\n v_cndmask_b32_e32 %6, %6, %8, vcc\n v_cndmask_b32_e32 %7, %7, %8, vcc"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x) : "vcc");)
+    } else if constexpr (KIND == 39) {  // v_max_i32_e32
+      REP8(asm volatile("v_max_i32_e32 %0, %0, %8\n v_max_i32_e32 %1, %1, %8\n v_max_i32_e32 %2, %2, %8\n v_max_i32_e32 %3, %3, %8\n v_max_i32_e32 %4, %4, %8\n v_max_i32_e32 %5, %5, %8\n v_max_i32_e32 %6, %6, %8\n v_max_i32_e32 %7, %7, %8"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x));)
+    } else if constexpr (KIND == 40) {  // v_min_u32_e32
+      REP8(asm volatile("v_min_u32_e32 %0, %0, %8\n v_min_u32_e32 %1, %1, %8\n v_min_u32_e32 %2, %2, %8\n v_min_u32_e32 %3, %3, %8\n v_min_u32_e32 %4, %4, %8\n v_min_u32_e32 %5, %5, %8\n v_min_u32_e32 %6, %6, %8\n v_min_u32_e32 %7, %7, %8"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x));)
+    } else if constexpr (KIND == 41) {  // v_add_f32_e64
+      REP8(asm volatile("v_add_f32_e64 %0, %0, %8\n v_add_f32_e64 %1, %1, %8\n v_add_f32_e64 %2, %2, %8\n v_add_f32_e64 %3, %3, %8\n v_add_f32_e64 %4, %4, %8\n v_add_f32_e64 %5, %5, %8\n v_add_f32_e64 %6, %6, %8\n v_add_f32_e64 %7, %7, %8"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x));)
+    } else if constexpr (KIND == 42) {  // v_fmac_f32_e32
+      REP8(asm volatile("v_fmac_f32_e32 %0, %8, %9\n v_fmac_f32_e32 %1, %8, %9\n v_fmac_f32_e32 %2, %8, %9\n v_fmac_f32_e32 %3, %8, %9\n v_fmac_f32_e32 %4, %8, %9\n v_fmac_f32_e32 %5, %8, %9\n v_fmac_f32_e32 %6, %8, %9\n v_fmac_f32_e32 %7, %8, %9"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x), "v"(c.x));)
+    } else if constexpr (KIND == 43) {  // v_mul_i32_i24_e32
+      REP8(asm volatile("v_mul_i32_i24_e32 %0, %0, %8\n v_mul_i32_i24_e32 %1, %1, %8\n v_mul_i32_i24_e32 %2, %2, %8\n v_mul_i32_i24_e32 %3, %3, %8\n v_mul_i32_i24_e32 %4, %4, %8\n v_mul_i32_i24_e32 %5, %5, %8\n v_mul_i32_i24_e32 %6, %6, %8\n v_mul_i32_i24_e32 %7, %7, %8"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x));)
+    } else if constexpr (KIND == 44) {  // v_mul_lo_u32
+      REP8(asm volatile("v_mul_lo_u32 %0, %0, %8\n v_mul_lo_u32 %1, %1, %8\n v_mul_lo_u32 %2, %2, %8\n v_mul_lo_u32 %3, %3, %8\n v_mul_lo_u32 %4, %4, %8\n v_mul_lo_u32 %5, %5, %8\n v_mul_lo_u32 %6, %6, %8\n v_mul_lo_u32 %7, %7, %8"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x));)
+    } else if constexpr (KIND == 45) {  // v_and_or_b32
+      REP8(asm volatile("v_and_or_b32 %0, %0, %8, %9\n v_and_or_b32 %1, %1, %8, %9\n v_and_or_b32 %2, %2, %8, %9\n v_and_or_b32 %3, %3, %8, %9\n v_and_or_b32 %4, %4, %8, %9\n v_and_or_b32 %5, %5, %8, %9\n v_and_or_b32 %6, %6, %8, %9\n v_and_or_b32 %7, %7, %8, %9"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x), "v"(c.x));)
+    } else if constexpr (KIND == 46) {  // v_lshl_or_b32
+      REP8(asm volatile("v_lshl_or_b32 %0, %0, %8, %9\n v_lshl_or_b32 %1, %1, %8, %9\n v_lshl_or_b32 %2, %2, %8, %9\n v_lshl_or_b32 %3, %3, %8, %9\n v_lshl_or_b32 %4, %4, %8, %9\n v_lshl_or_b32 %5, %5, %8, %9\n v_lshl_or_b32 %6, %6, %8, %9\n v_lshl_or_b32 %7, %7, %8, %9"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x), "v"(c.x));)
+    } else if constexpr (KIND == 47) {  // v_bfi_b32
+      REP8(asm volatile("v_bfi_b32 %0, %0, %8, %9\n v_bfi_b32 %1, %1, %8, %9\n v_bfi_b32 %2, %2, %8, %9\n v_bfi_b32 %3, %3, %8, %9\n v_bfi_b32 %4, %4, %8, %9\n v_bfi_b32 %5, %5, %8, %9\n v_bfi_b32 %6, %6, %8, %9\n v_bfi_b32 %7, %7, %8, %9"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x), "v"(c.x));)
+    } else if constexpr (KIND == 48) {  // v_alignbit_b32
+      REP8(asm volatile("v_alignbit_b32 %0, %0, %8, %9\n v_alignbit_b32 %1, %1, %8, %9\n v_alignbit_b32 %2, %2, %8, %9\n v_alignbit_b32 %3, %3, %8, %9\n v_alignbit_b32 %4, %4, %8, %9\n v_alignbit_b32 %5, %5, %8, %9\n v_alignbit_b32 %6, %6, %8, %9\n v_alignbit_b32 %7, %7, %8, %9"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x), "v"(c.x));)
+    } else if constexpr (KIND == 49) {  // v_max_f32_e32
+      REP8(asm volatile("v_max_f32_e32 %0, %0, %8\n v_max_f32_e32 %1, %1, %8\n v_max_f32_e32 %2, %2, %8\n v_max_f32_e32 %3, %3, %8\n v_max_f32_e32 %4, %4, %8\n v_max_f32_e32 %5, %5, %8\n v_max_f32_e32 %6, %6, %8\n v_max_f32_e32 %7, %7, %8"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x));)
+    } else if constexpr (KIND == 50) {  // v_sub_f32_e32
+      REP8(asm volatile("v_sub_f32_e32 %0, %0, %8\n v_sub_f32_e32 %1, %1, %8\n v_sub_f32_e32 %2, %2, %8\n v_sub_f32_e32 %3, %3, %8\n v_sub_f32_e32 %4, %4, %8\n v_sub_f32_e32 %5, %5, %8\n v_sub_f32_e32 %6, %6, %8\n v_sub_f32_e32 %7, %7, %8"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x));)
+    } else if constexpr (KIND == 52) {  // v_xor_b32_e64
+      REP8(asm volatile("v_xor_b32_e64 %0, %0, %8\n v_xor_b32_e64 %1, %1, %8\n v_xor_b32_e64 %2, %2, %8\n v_xor_b32_e64 %3, %3, %8\n v_xor_b32_e64 %4, %4, %8\n v_xor_b32_e64 %5, %5, %8\n v_xor_b32_e64 %6, %6, %8\n v_xor_b32_e64 %7, %7, %8"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x));)
+    } else if constexpr (KIND == 53) {  // v_max_u32_e32
+      REP8(asm volatile("v_max_u32_e32 %0, %0, %8\n v_max_u32_e32 %1, %1, %8\n v_max_u32_e32 %2, %2, %8\n v_max_u32_e32 %3, %3, %8\n v_max_u32_e32 %4, %4, %8\n v_max_u32_e32 %5, %5, %8\n v_max_u32_e32 %6, %6, %8\n v_max_u32_e32 %7, %7, %8"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x));)
+    } else if constexpr (KIND == 54) {  // v_pk_max_i16
+      REP8(asm volatile("v_pk_max_i16 %0, %0, %8\n v_pk_max_i16 %1, %1, %8\n v_pk_max_i16 %2, %2, %8\n v_pk_max_i16 %3, %3, %8\n v_pk_max_i16 %4, %4, %8\n v_pk_max_i16 %5, %5, %8\n v_pk_max_i16 %6, %6, %8\n v_pk_max_i16 %7, %7, %8"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x));)
+    } else if constexpr (KIND == 55) {  // v_cvt_f32_i32_e32
+      REP8(asm volatile("v_cvt_f32_i32_e32 %0, %0\n v_cvt_f32_i32_e32 %1, %1\n v_cvt_f32_i32_e32 %2, %2\n v_cvt_f32_i32_e32 %3, %3\n v_cvt_f32_i32_e32 %4, %4\n v_cvt_f32_i32_e32 %5, %5\n v_cvt_f32_i32_e32 %6, %6\n v_cvt_f32_i32_e32 %7, %7"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x));)
+    } else if constexpr (KIND == 56) {  // v_rcp_f32_e32
+      REP8(asm volatile("v_rcp_f32_e32 %0, %0\n v_rcp_f32_e32 %1, %1\n v_rcp_f32_e32 %2, %2\n v_rcp_f32_e32 %3, %3\n v_rcp_f32_e32 %4, %4\n v_rcp_f32_e32 %5, %5\n v_rcp_f32_e32 %6, %6\n v_rcp_f32_e32 %7, %7"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x));)
+    } else if constexpr (KIND == 57) {  // v_lshl_add_u32
+      REP8(asm volatile("v_lshl_add_u32 %0, %0, %8, %9\n v_lshl_add_u32 %1, %1, %8, %9\n v_lshl_add_u32 %2, %2, %8, %9\n v_lshl_add_u32 %3, %3, %8, %9\n v_lshl_add_u32 %4, %4, %8, %9\n v_lshl_add_u32 %5, %5, %8, %9\n v_lshl_add_u32 %6, %6, %8, %9\n v_lshl_add_u32 %7, %7, %8, %9"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x), "v"(c.x));)
+    } else if constexpr (KIND == 58) {  // v_med3_i32
+      REP8(asm volatile("v_med3_i32 %0, %0, %8, %9\n v_med3_i32 %1, %1, %8, %9\n v_med3_i32 %2, %2, %8, %9\n v_med3_i32 %3, %3, %8, %9\n v_med3_i32 %4, %4, %8, %9\n v_med3_i32 %5, %5, %8, %9\n v_med3_i32 %6, %6, %8, %9\n v_med3_i32 %7, %7, %8, %9"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x), "v"(c.x));)
+    } else if constexpr (KIND == 59) {  // v_min3_f32
+      REP8(asm volatile("v_min3_f32 %0, %0, %8, %9\n v_min3_f32 %1, %1, %8, %9\n v_min3_f32 %2, %2, %8, %9\n v_min3_f32 %3, %3, %8, %9\n v_min3_f32 %4, %4, %8, %9\n v_min3_f32 %5, %5, %8, %9\n v_min3_f32 %6, %6, %8, %9\n v_min3_f32 %7, %7, %8, %9"
+                        : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x), "v"(c.x));)
     } else if constexpr (KIND == 5) {  // ds_write_b64, lane-contiguous
       REP8(asm volatile("ds_write_b64 %0, %1\n ds_write_b64 %0, %2 offset:2048\n ds_write_b64 %0, %3 offset:4096\n ds_write_b64 %0, %4 offset:6144\n"
                         "ds_write_b64 %0, %5 offset:8192\n ds_write_b64 %0, %6 offset:10240\n ds_write_b64 %0, %7 offset:12288\n ds_write_b64 %0, %8 offset:14336\n s_waitcnt lgkmcnt(0)"
@@ -116,14 +203,20 @@ void run(const char* name, int per_iter) {
   for (int threads : {256, 512, 1024}) {   // 1, 2, 4 waves per SIMD (one block per CU, all 256 CUs)
     const int iters = 200;
     hipMemset(d, 0, 256 * 16 * 8);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    bench<KIND><<<256, threads, 20480>>>(d, sink, iters);   // warm (code in the instruction cache)
+    hipEventRecord(e0);
     bench<KIND><<<256, threads, 20480>>>(d, sink, iters);
+    hipEventRecord(e1);
     hipDeviceSynchronize();
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     std::vector<unsigned long long> h(256 * 16);
     hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
     double sum = 0; int n = 0;
     for (int b = 0; b < 256; ++b) for (int w = 0; w < threads / 64; ++w) { sum += (double)h[b * 16 + w]; ++n; }
     const double cyc = sum / n / iters / per_iter;   // cycles of wave time per instruction
-    printf("%-34s %d waves/SIMD: %6.2f cycles per wave-instruction, %6.2f per SIMD slot\n", name, threads / 256, cyc, cyc / (threads / 256));
+    // s_memtime ticks against the wall clock of the launch (~ the longest wave + launch overhead): ns per tick
+    printf("%-34s %d waves/SIMD: %6.2f cycles per wave-instruction, %6.2f per SIMD slot   (launch %.1f us, %.2f ns per tick)\n", name, threads / 256, cyc, cyc / (threads / 256), ms * 1e3, ms * 1e6 / (sum / n));
   }
   hipFree(d); hipFree(sink);
 }
@@ -136,5 +229,34 @@ int main() {
   run<12>("v_dot2_i32_i16", 64); run<13>("v_dot2c_i32_i16", 64); run<14>("v_pk_add_u16", 64); run<15>("v_bfe_u32", 64);
   run<16>("v_perm_b32", 64); run<17>("v_add_lshl_u32", 64); run<18>("v_pk_ashrrev_i16", 64); run<19>("v_xor_b32", 64);
   run<20>("v_add3_u32", 64); run<21>("v_mad_i32_i24", 64);
+  run<30>("v_add_u32_e32", 64);
+  run<31>("v_sub_u32_e32", 64);
+  run<32>("v_and_b32_e32", 64);
+  run<33>("v_or_b32_e32", 64);
+  run<34>("v_lshlrev_b32_e32", 64);
+  run<35>("v_ashrrev_i32_e32", 64);
+  run<36>("v_mul_f32_e32", 64);
+  run<37>("v_mov_b32_e32", 64);
+  run<38>("v_cndmask_b32_e32", 64);
+  run<39>("v_max_i32_e32", 64);
+  run<40>("v_min_u32_e32", 64);
+  run<41>("v_add_f32_e64", 64);
+  run<42>("v_fmac_f32_e32", 64);
+  run<43>("v_mul_i32_i24_e32", 64);
+  run<44>("v_mul_lo_u32", 64);
+  run<45>("v_and_or_b32", 64);
+  run<46>("v_lshl_or_b32", 64);
+  run<47>("v_bfi_b32", 64);
+  run<48>("v_alignbit_b32", 64);
+  run<49>("v_max_f32_e32", 64);
+  run<50>("v_sub_f32_e32", 64);
+  run<52>("v_xor_b32_e64", 64);
+  run<53>("v_max_u32_e32", 64);
+  run<54>("v_pk_max_i16", 64);
+  run<55>("v_cvt_f32_i32_e32", 64);
+  run<56>("v_rcp_f32_e32", 64);
+  run<57>("v_lshl_add_u32", 64);
+  run<58>("v_med3_i32", 64);
+  run<59>("v_min3_f32", 64);
   return 0;
 }
