@@ -243,8 +243,10 @@ doppler_mag_pair_kernel(const f32x2* __restrict__ in, float* __restrict__ mag, u
 // ---------------------------------------------------------------- FIXED16 passes (build extension, oracle: orc_rd_fixed)
 // The same two passes on the 16-bit FixedPoint data path: beats {re[31:16], im[15:0]} in, the range spectrum kept as
 // beats (4 B/cell), both FFTs with the stage-exact arithmetic of fft_fx_frame (Q2.14 ROM in LDS), Q1.15 windows,
-// magnitudes (mag_fx) as int32.
-template <int M>
+// magnitudes (mag_fx) as int32.  FX = the trim path of the fixed-point FFT (0 convergent, 1 floor / half-up), one
+// instantiation each: a kernel holding every path of fft_fx_frame carries the registers of the stage-option path
+// (154-182 VGPRs, two waves per SIMD), which the 2-D chain never takes (rejected on the host).
+template <int M, int FX>
 __global__ void __launch_bounds__(wg_size(M))
 range_fx_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n_rows, uint32_t nd, uint32_t tile,
                 const uint32_t* __restrict__ twq, ChainRegs rg, uint32_t* __restrict__ zero_count) {
@@ -275,7 +277,7 @@ range_fx_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uin
   }
   fx_rom_fill(rom, twq, N / 2, tid, wg_size(M));
   __syncthreads();
-  fft_fx_frame<M>(xr, xi, tau, fbase, rom, rg);
+  fft_fx_frame<M, FX>(xr, xi, tau, fbase, rom, rg);
   constexpr int NP = plan_np(M), WL = plan_w(M, NP - 1);
   if (!live) return;
   const uint32_t ch = row / nd, d = row % nd;
@@ -294,7 +296,7 @@ range_fx_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uin
 constexpr int kFxCols = 16;  // range bins per workgroup of the FIXED16 Doppler pass
 constexpr int kFxColBytes(int MD) { return 4 * fft_image_slots(MD) + (MD >= 10 ? 16 : 8); }  // column skew: as kColBytes, for 4-byte slots
 
-template <int MD>
+template <int MD, int FX>
 __global__ void __launch_bounds__(threads_per_frame(MD) * kFxCols)
 doppler_fx_kernel(const uint32_t* __restrict__ in, int32_t* __restrict__ mag, uint32_t nr, uint32_t tile,
                   const uint32_t* __restrict__ twq, const int16_t* __restrict__ win, const int16_t* __restrict__ log_lut,
@@ -327,7 +329,7 @@ doppler_fx_kernel(const uint32_t* __restrict__ in, int32_t* __restrict__ mag, ui
   }
   fx_rom_fill(rom, twq, ND / 2, tid, T * C);
   __syncthreads();
-  fft_fx_frame<MD>(xr, xi, tau, fbase, rom, rg);
+  fft_fx_frame<MD, FX>(xr, xi, tau, fbase, rom, rg);
   constexpr int NP = plan_np(MD), WL = plan_w(MD, NP - 1);
   int32_t* dst = mag + (size_t)ch * ND * nr + map_index<kMagTileCols>(0, r0 + fl, ND, nr, tile);
   const uint32_t mpitch = tile ? kMagTileCols : nr;
@@ -790,14 +792,40 @@ cfar2d_walk_kernel(const S* __restrict__ mag, uint32_t* __restrict__ out, uint32
           det_list[base + k] = d;
         }
       }
-    } else if (n > (uint32_t)kWalkStage && owner) {
-      // more peaks than the staging holds (a wave's 2 x 64 x SEG cells with > kWalkStage peaks: thresholds far
-      // below the noise): every lane reads its own words back and appends them one by one
+    } else if (n > (uint32_t)kWalkStage) {
+      // more peaks than the staging holds (thresholds near the noise floor): every lane reads its own words back,
+      // the wave takes its n entries with ONE reservation (n is exact: the staging counter kept counting) and a lane
+      // writes its peaks behind those of the lanes before it.  (One atomic per PEAK here cost 460 us per 117 k peaks.)
+      uint32_t mine = 0u;
+      if (owner) {
 #pragma unroll 1
-      for (int i = 0; i < SEG; ++i) {
-        const u32x2 wd = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_out, voff_out, (uint32_t)(d0 + i) * nr * 4u, 1 /* glc */));
-        if (wd.x & 1u) append_peak(det_list, det_cap, det_count, ch_base + ch, (uint32_t)(d0 + i), (uint32_t)col, wd.x);
-        if (wd.y & 1u) append_peak(det_list, det_cap, det_count, ch_base + ch, (uint32_t)(d0 + i), (uint32_t)col + 1u, wd.y);
+        for (int i = 0; i < SEG; ++i) {
+          const u32x2 wd = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_out, voff_out, (uint32_t)(d0 + i) * nr * 4u, 1 /* glc */));
+          mine += (wd.x & 1u) + (wd.y & 1u);
+        }
+      }
+      uint32_t incl = mine;
+#pragma unroll
+      for (int sh = 1; sh < 64; sh <<= 1) {
+        const uint32_t t = __shfl_up(incl, sh);
+        if (lane >= sh) incl += t;
+      }
+      uint32_t base = 0u;
+      if (lane == 0) base = reserve_peaks(det_count, det_cap, n);
+      uint32_t pos = __builtin_amdgcn_readfirstlane(base) + incl - mine;
+      if (owner && mine) {
+#pragma unroll 1
+        for (int i = 0; i < SEG; ++i) {
+          const u32x2 wd = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_out, voff_out, (uint32_t)(d0 + i) * nr * 4u, 1 /* glc */));
+          if (wd.x & 1u) {
+            if (pos < det_cap) det_list[pos] = rsp_detection{ch_base + ch, (uint32_t)col, (uint32_t)(d0 + i), wd.x};
+            ++pos;
+          }
+          if (wd.y & 1u) {
+            if (pos < det_cap) det_list[pos] = rsp_detection{ch_base + ch, (uint32_t)col + 1u, (uint32_t)(d0 + i), wd.y};
+            ++pos;
+          }
+        }
       }
     }
   }
@@ -922,25 +950,29 @@ static hipError_t launch_range_fx(const uint32_t* in, uint32_t* out, uint32_t n_
                                   const uint32_t* twq, const ChainRegs& rg, uint32_t* zero_count, hipStream_t s, int device) {
   constexpr int fpw = frames_per_wg(M);
   const size_t lds = (((size_t)fpw * fft_image_slots(M) * 4 + 7) & ~size_t(7)) + fx_rom_bytes(M);
-  auto k = range_fx_kernel<M>;
-  static LdsGrant granted;
-  hipError_t e = grant_lds(k, lds, device, granted);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k, dim3((n_rows + fpw - 1) / fpw), dim3(wg_size(M)), lds, s, in, out, n_rows, nd, tile, twq, rg, zero_count);
-  return hipGetLastError();
+  auto go = [&](auto k, LdsGrant& granted) -> hipError_t {
+    hipError_t e = grant_lds(k, lds, device, granted);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3((n_rows + fpw - 1) / fpw), dim3(wg_size(M)), lds, s, in, out, n_rows, nd, tile, twq, rg, zero_count);
+    return hipGetLastError();
+  };
+  static LdsGrant g2[2];
+  return rg.trim_conv ? go(range_fx_kernel<M, 0>, g2[0]) : go(range_fx_kernel<M, 1>, g2[1]);
 }
 template <int MD>
 static hipError_t launch_doppler_fx(const uint32_t* in, int32_t* mag, uint32_t n_ch, uint32_t nr, uint32_t tile,
                                     const uint32_t* twq, const int16_t* win, const int16_t* log_lut, const ChainRegs& rg,
                                     hipStream_t s, int device) {
   const size_t lds = (((size_t)kFxColBytes(MD) * kFxCols + 7) & ~size_t(7)) + fx_rom_bytes(MD);
-  auto k = doppler_fx_kernel<MD>;
-  static LdsGrant granted;
-  hipError_t e = grant_lds(k, lds, device, granted);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k, dim3(n_ch * (nr / kFxCols)), dim3(threads_per_frame(MD) * kFxCols), lds, s, in, mag, nr, tile, twq, win,
-                     log_lut, rg);
-  return hipGetLastError();
+  auto go = [&](auto k, LdsGrant& granted) -> hipError_t {
+    hipError_t e = grant_lds(k, lds, device, granted);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(n_ch * (nr / kFxCols)), dim3(threads_per_frame(MD) * kFxCols), lds, s, in, mag, nr, tile, twq, win,
+                       log_lut, rg);
+    return hipGetLastError();
+  };
+  static LdsGrant g2[2];
+  return rg.trim_conv ? go(doppler_fx_kernel<MD, 0>, g2[0]) : go(doppler_fx_kernel<MD, 1>, g2[1]);
 }
 
 static hipError_t launch_rd2d_chunk_fx(const Rd2dLaunch& a, uint32_t ch0, uint32_t n_ch) {
