@@ -95,6 +95,11 @@ class SclkReader:
         return None
 
 
+CFG2_CAP = 1 << 15
+RD_CAP = 1 << 16
+GATHER_EVERY = 8   # N > 1, cfg 2: detection lists per RCCL all-gather
+
+
 def median(v):
     s = sorted(v)
     return s[len(s) // 2]
@@ -121,7 +126,7 @@ class Fence:
         return float(t.item())
 
 
-def timed_blocks(step, steps, warmup, fence, first=0, sclk=None):
+def timed_blocks(step, steps, warmup, fence, first=0, sclk=None, flush=None):
     """warm-up, pre-heat to a stationary step time, then N_BLOCKS blocks of `reps` passes over `steps` steps.
     Returns a dict: per-block seconds PER STEP (max over ranks), reps, the clock readings, the next step index."""
     i = first
@@ -159,6 +164,8 @@ def timed_blocks(step, steps, warmup, fence, first=0, sclk=None):
         for _ in range(reps * steps):
             step(i)
             i += 1
+        if flush:
+            flush(i)   # inside the timed region: lists not yet gathered (a partial batch) travel before the clock stops
         fence()
         dt = time.perf_counter() - t0
         clocks.append([c0, sclk() if sclk else None])
@@ -237,7 +244,7 @@ def synth_maps(torch, dev, g, n_ch, nd, nr):
     return x.contiguous()
 
 
-def make_cfg2(R, torch, dev, local_rank, rank, n=4096, frames=4096):
+def make_cfg2(R, torch, dev, local_rank, rank, n=4096, frames=4096, lists=None):
     params = R.FftMagCfarVanillaParameters(
         fftParams=R.FFTParams.fixed(numPoints=n), magParams=R.MAGParams.fixed(),
         cfarParams=R.CFARParams(fftSize=n), dtype=R.F32, device=local_rank)
@@ -249,21 +256,21 @@ def make_cfg2(R, torch, dev, local_rank, rank, n=4096, frames=4096):
     g.manual_seed(1234 + rank)
     ins = [synth_frames(torch, dev, g, frames, n) for _ in range(N_SETS)]
     outs = [torch.empty(frames, n, dtype=torch.int32, device=dev) for _ in range(N_SETS)]
-    cap = 1 << 15  # list capacity per step (expected ~13 k peaks): 512 KiB
-    lists = [torch.zeros(cap + 1, 4, dtype=torch.int32, device=dev) for _ in range(N_SETS)]  # row 0 = {found, stored}
+    cap = CFG2_CAP  # list capacity per step (expected ~13 k peaks): 512 KiB
+    if lists is None:
+        lists = [torch.zeros(cap + 1, 4, dtype=torch.int32, device=dev) for _ in range(N_SETS)]  # row 0 = {found, stored}
 
     def step(i):
-        s = i % N_SETS
-        dut.process_detect_device(ins[s].data_ptr(), frames, outs[s].data_ptr(), lists[s][1:].data_ptr(), cap,
-                                  lists[s][0].data_ptr())
+        s, lst = i % N_SETS, lists[i % len(lists)]
+        dut.process_detect_device(ins[s].data_ptr(), frames, outs[s].data_ptr(), lst[1:].data_ptr(), cap, lst[0].data_ptr())
 
     name = (f"cfg2: 1-ch {n}-pt range FFT + JPL logMag + CA-CFAR (R=32,G=4), {frames}-chirp batch, fp32, "
             "dense words + detection list")
     return dict(dut=dut, step=step, cells=n * frames, bytes=12.0 * n * frames, kernel=f"chain1d_quad_kernel<{n.bit_length() - 1},f32>",
-                name=name, ins=ins, lists=lists, n=n, frames=frames)
+                name=name, ins=ins, lists=lists, n=n, frames=frames, cap=cap)
 
 
-def make_rd(R, torch, dev, local_rank, rank, nr, nd, n_ch, tag, sets=N_SETS, with_list=True):
+def make_rd(R, torch, dev, local_rank, rank, nr, nd, n_ch, tag, sets=N_SETS, with_list=True, lists=None):
     params = R.FftMagCfarVanillaParameters(
         fftParams=R.FFTParams.fixed(numPoints=nr), magParams=R.MAGParams.fixed(),
         cfarParams=R.CFARParams(fftSize=nr, leadLaggWindowSize=16), dtype=R.F32, device=local_rank,
@@ -278,14 +285,14 @@ def make_rd(R, torch, dev, local_rank, rank, nr, nd, n_ch, tag, sets=N_SETS, wit
     ins = [synth_maps(torch, dev, g, n_ch, nd, nr) for _ in range(sets)]
     cells = int(np.prod(shape))
     outs = [torch.empty(cells, dtype=torch.int32, device=dev) for _ in range(sets)]
-    cap = 1 << 16
-    lists = [torch.zeros(cap + 1, 4, dtype=torch.int32, device=dev) for _ in range(sets)]
+    cap = RD_CAP
+    if lists is None:
+        lists = [torch.zeros(cap + 1, 4, dtype=torch.int32, device=dev) for _ in range(sets)]
 
     def step(i):
-        s = i % sets
+        s, lst = i % sets, lists[i % len(lists)]
         if with_list:   # the CFAR kernel appends its peaks itself: no second pass over the dense words
-            dut.process_detect_device(ins[s].data_ptr(), n_ch, outs[s].data_ptr(), lists[s][1:].data_ptr(), cap,
-                                      lists[s][0].data_ptr())
+            dut.process_detect_device(ins[s].data_ptr(), n_ch, outs[s].data_ptr(), lst[1:].data_ptr(), cap, lst[0].data_ptr())
         else:
             dut.process_device(ins[s].data_ptr(), n_ch, outs[s].data_ptr())
 
@@ -408,7 +415,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--workload", default=None, choices=[None, "cfg2", "cfg5"],
-                    help="override: cfg2 weak-scaled on N ranks / cfg5 on one rank (rehearsals); default = cfg2 at N = 1, cfg5 at N > 1")
+                    help="default cfg2 (configs[1]) per GPU at every N, + configs[4] as extra.cfg5 at N > 1; cfg5 = configs[4] as the line itself")
     args = ap.parse_args()
 
     import torch
@@ -437,7 +444,9 @@ def main():
     assert main_stream.cuda_stream != 0
     fence = Fence(torch, dist, use_dist, dev)
     sclk = SclkReader(torch, dev)
-    workload = args.workload or ("cfg2" if world == 1 and not use_dist else "cfg5")
+    # the SAME per-GPU workload at every N (value(N) / value(1) is then a scaling efficiency); at N > 1 the line also
+    # carries BASELINE.json configs[4] (cfg 5) as extra.cfg5
+    workload = args.workload or "cfg2"
     if workload == "cfg5":
         line = run_cfg5(args, torch, dist, R, rank, local_rank, world, dev, use_dist, main_stream, fence, sclk)
     else:
@@ -449,16 +458,121 @@ def main():
         dist.destroy_process_group()
 
 
+class GatherLeg:
+    """The only exchange of the N > 1 path: the RCCL all-gather of the packed detection lists (row 0 = {found, stored}),
+    issued on a side stream under the following steps' kernels and sized to the lists (dist.PackedGatherer).
+    every = K: the lists of K consecutive steps travel in ONE collective (dist.gather_packed_batch; double-buffered
+    batches of K list slots, the chain writes step i's list straight into slot i % K); K = 1: one collective per step."""
+
+    def __init__(self, torch, dev, world, main_stream, cap, enabled, every=1):
+        from rsp_chains_amd.dist import PackedGatherer
+        self.torch, self.main, self.cap, self.on, self.k = torch, main_stream, cap, enabled, every
+        self.batches = [torch.zeros(every, cap + 1, 4, dtype=torch.int32, device=dev) for _ in range(2)]
+        self.lists = [self.batches[b][j] for b in range(2) for j in range(every)]   # list of step i = lists[i % (2 K)]
+        self.pg = PackedGatherer(cap) if enabled else None
+        self.last = 0
+        if enabled:
+            self.comm = torch.cuda.Stream(device=dev)
+            self.stage = torch.empty(every * (cap + 1), 4, dtype=torch.int32, device=dev)
+            self.g_out = [torch.empty(world * every * (cap + 1), 4, dtype=torch.int32, device=dev) for _ in range(2)]
+            self.ready = [torch.cuda.Event() for _ in range(2)]
+            self.gathered = [torch.cuda.Event() for _ in range(2)]
+            self.views = [None, None]
+
+    def _gather(self, b):
+        self.ready[b].record(self.main)
+        with self.torch.cuda.stream(self.comm):
+            self.comm.wait_event(self.ready[b])
+            self.views[b] = self.pg.gather_batch(self.batches[b], out=self.g_out[b], stage=self.stage)
+            self.gathered[b].record(self.comm)
+
+    def wrap(self, inner):
+        def step(i):
+            b = (i // self.k) % 2
+            if self.on and i % self.k == 0 and self.views[b] is not None:
+                self.main.wait_event(self.gathered[b])   # do not overwrite a batch still being gathered
+            inner(i)
+            if self.on and (i + 1) % self.k == 0:
+                self._gather(b)
+                self.last = i + 1
+        return step
+
+    def flush(self, i):
+        """lists of steps [last, i) are still local: gather their (partial) batch"""
+        if self.on and i > self.last and i % self.k != 0:
+            self._gather((i // self.k) % 2)
+            self.last = i
+
+    def size_payload(self, step, fence):
+        """off the clock: a few steps, read their headers, grow the travelling row count if a list did not fit"""
+        if not self.on:
+            return
+        for i in range(2 * self.k):
+            step(i)
+        fence()
+        for v in self.views:
+            self.pg.settle(v)
+
+    def complete(self, fence):
+        """every list of the last gathered batches fitted the rows that travelled?"""
+        if not self.on:
+            return True
+        fence()
+        return all(self.pg.settle(v) for v in self.views if v is not None)
+
+    def alone_ms(self, fence):
+        if not self.on:
+            return None
+        fence()
+        t0 = time.perf_counter()
+        for j in range(20):
+            self.pg.gather_batch(self.batches[j % 2], out=self.g_out[j % 2], stage=self.stage)
+        fence()
+        return fence.max_over_ranks(time.perf_counter() - t0) / 20 * 1e3
+
+    def report(self, gather_ms, sec_without, complete):
+        return {"lists_per_collective": self.k, "ms_per_collective_alone": gather_ms,
+                "ms_per_step_without_gather": sec_without * 1e3,
+                "rows_per_list": self.pg.rows if self.on else None,
+                "bytes_per_rank_per_collective": self.pg.rows * 16 * self.k if self.on else None,
+                "capacity_rows": self.cap + 1, "every_gathered_list_complete": complete}
+
+
 def run_cfg2(args, torch, dist, R, rank, local_rank, world, dev, use_dist, main_stream, fence, sclk):
-    w = make_cfg2(R, torch, dev, local_rank, rank)
-    dut, step = w["dut"], w["step"]
+    # N > 1: the same batch on every GPU (chirps shard across ranks; weak scaling).  A 49-us step cannot hide a collective
+    # of its own (12 us per step on a 1-rank group: launch latency + the CU share of the RCCL kernel), so the lists of
+    # GATHER_EVERY steps travel in one all-gather; the per-step form is measured beside it.
+    leg = GatherLeg(torch, dev, world, main_stream, CFG2_CAP, use_dist, every=GATHER_EVERY if use_dist else 1)
+    w = make_cfg2(R, torch, dev, local_rank, rank, lists=leg.lists if use_dist else None)
+    dut = w["dut"]
     dut.set_stream(main_stream.cuda_stream)
-    tb = timed_blocks(step, args.steps, args.warmup, fence, sclk=sclk)
+    step = leg.wrap(w["step"])
+    leg.size_payload(step, fence)
+    tb = timed_blocks(step, args.steps, args.warmup, fence, sclk=sclk, flush=leg.flush)
     nxt = tb["next"]
-    kms, launches = kernel_ms(dut, step, args.steps * tb["reps"], nxt, fence)
     per = tb["per_step_s"]
     sec = median(per)
-    found, stored = (int(v) for v in w["lists"][(nxt - 1) % N_SETS][0, :2].tolist())
+    gather_rep = None
+    if use_dist:
+        complete = leg.complete(fence)
+        leg.on = False   # the same steps without the collective: what the gather costs end to end
+        tb_ng = timed_blocks(step, args.steps, 1, fence, first=nxt)
+        nxt = tb_ng["next"]
+        leg.on = True
+        gather_rep = leg.report(leg.alone_ms(fence), median(tb_ng["per_step_s"]), complete)
+        leg.on = False
+        # one collective per step, for comparison
+        leg1 = GatherLeg(torch, dev, world, main_stream, CFG2_CAP, True, every=1)
+        w1 = make_cfg2(R, torch, dev, local_rank, rank, lists=leg1.lists)
+        w1["dut"].set_stream(main_stream.cuda_stream)
+        step1 = leg1.wrap(w1["step"])
+        leg1.size_payload(step1, fence)
+        tb1 = timed_blocks(step1, args.steps, 2, fence, first=2, flush=leg1.flush)
+        gather_rep["ms_per_step_with_one_collective_per_step"] = median(tb1["per_step_s"]) * 1e3
+        del leg1, w1, step1
+        torch.cuda.empty_cache()
+    kms, launches = kernel_ms(dut, w["step"], args.steps * tb["reps"], nxt, fence)
+    found, stored = (int(v) for v in w["lists"][(nxt - 1) % len(w["lists"])][0, :2].tolist())
     line = None
     if rank == 0:
         traffic, src = static_traffic("chain1d_hbm_bytes_per_launch")
@@ -471,11 +585,24 @@ def run_cfg2(args, torch, dist, R, rank, local_rank, world, dev, use_dist, main_
             "preheat_ms": tb["preheat_s"] * 1e3,
             "timing": (f"pre-heated to a stationary step time, then {N_BLOCKS} blocks of block_reps x steps steps (>= 50 ms each); "
                        "value = median block (sustained), best_block = fastest; sclk_mhz = driver-reported shader clock before / after each block"),
-            "config": {"workload": w["name"], "cells_per_step_per_gpu": w["cells"], "buffer_sets": N_SETS,
+            "config": {"workload": w["name"] + ("" if not use_dist else f"; the same batch on each of {world} GPUs (chirps shard "
+                                                f"across ranks, weak scaling) + ONE RCCL all-gather of the packed detection lists per {GATHER_EVERY} steps, side stream"),
+                       "cells_per_step_per_gpu": w["cells"], "buffer_sets": N_SETS,
                        "detections_last_step": {"found": found, "stored": stored}},
             "roofline": roofline(w["kernel"], kms, w["bytes"], traffic, src),
         }
         line["roofline"]["kernel_ms_launches"] = launches
+        if use_dist:
+            line["gather"] = gather_rep
+            line["per_gpu_value"] = w["cells"] / sec
+    if use_dist and not args.no_extra:
+        # BASELINE.json configs[4] (64 Rx sharded 8 per GPU at N = 8) in the same run, as its own record
+        del w, dut, step, leg
+        torch.cuda.empty_cache()
+        sub = run_cfg5(args, torch, dist, R, rank, local_rank, world, dev, use_dist, main_stream, fence, sclk)
+        if rank == 0:
+            line["extra"] = {"cfg5": sub}
+        return line
     if world == 1 and not use_dist and not args.no_extra:
         x0 = w["ins"][0]
         host_sample = x0[:2048].cpu().numpy().view(np.complex64).reshape(2048, w["n"])
@@ -499,7 +626,7 @@ def run_cfg2(args, torch, dist, R, rank, local_rank, world, dev, use_dist, main_
         # the same per-GPU work the N > 1 lines run (8 Rx of 8192 x 1024 per GPU): the 1-GPU point of THAT scaling curve
         line["scaling_baseline"] = {"workload": extra["cfg5_share"]["workload"], "value": extra["cfg5_share"]["value"],
                                     "unit": "cells/s", "n_gpus": 1,
-                                    "note": "bench.py --gpus N (N > 1) runs this workload on every GPU (weak scaling); the headline `value` is configs[1]"}
+                                    "note": "the 1-GPU point of extra.cfg5 of the N > 1 lines (8 Rx of 8192 x 1024 per GPU, weak scaling); `value` is configs[1] per GPU at every N"}
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(host_sample, 4096, 4096)
             line["cpu_baseline_fixed"] = cpu_baseline_fixed()
@@ -508,63 +635,29 @@ def run_cfg2(args, torch, dist, R, rank, local_rank, world, dev, use_dist, main_
 
 def run_cfg5(args, torch, dist, R, rank, local_rank, world, dev, use_dist, main_stream, fence, sclk):
     """BASELINE.json configs[4] at N = 8: 8 Rx x 8192 x 1024 per GPU (64 Rx on eight), RCCL gather of the lists."""
-    from rsp_chains_amd.dist import PackedGatherer, shard_range
+    from rsp_chains_amd.dist import shard_range
     per_gpu, nr, nd = 8, 8192, 1024
     total_ch = per_gpu * world
     lo, hi = shard_range(total_ch, rank, world)
     n_ch = hi - lo
-    w = make_rd(R, torch, dev, local_rank, rank, nr, nd, n_ch, f"cfg5: {total_ch} Rx, {n_ch} per GPU", sets=2)
+    leg = GatherLeg(torch, dev, world, main_stream, RD_CAP, use_dist, every=1)   # a 0.5-ms step hides its own collective
+    w = make_rd(R, torch, dev, local_rank, rank, nr, nd, n_ch, f"cfg5: {total_ch} Rx, {n_ch} per GPU", sets=2,
+                lists=leg.lists if use_dist else None)
     dut, sets, cap = w["dut"], w["sets"], w["cap"]
     dut.set_stream(main_stream.cuda_stream)
-    lists = w["lists"]
-    gather = use_dist
-    if gather:
-        comm = torch.cuda.Stream(device=dev)
-        pg = PackedGatherer(cap)
-        g_lists = [torch.empty(world * (cap + 1), 4, dtype=torch.int32, device=dev) for _ in range(sets)]
-        ready = [torch.cuda.Event() for _ in range(sets)]
-        gathered = [torch.cuda.Event() for _ in range(sets)]
-        views = [None] * sets
-    state = {"gather": gather}
-
-    def step(i):
-        s = i % sets
-        if state["gather"] and i >= sets:
-            main_stream.wait_event(gathered[s])   # do not overwrite a list still being gathered
-        w["step"](i)
-        if state["gather"]:
-            ready[s].record(main_stream)
-            with torch.cuda.stream(comm):
-                comm.wait_event(ready[s])
-                views[s] = pg.gather(lists[s], out=g_lists[s])
-                gathered[s].record(comm)
-
-    if gather:  # size the payload to the lists (off the clock): two steps, read their headers, grow if needed
-        for i in range(sets):
-            step(i)
-        fence()
-        for v in views:
-            pg.settle(v)
-    tb = timed_blocks(step, args.steps, args.warmup, fence, sclk=sclk)
+    step = leg.wrap(w["step"])
+    leg.size_payload(step, fence)
+    tb = timed_blocks(step, args.steps, args.warmup, fence, sclk=sclk, flush=leg.flush)
     per = tb["per_step_s"]
     sec = median(per)
-    complete = True
-    if gather:  # every list of the timed steps fitted the rows that travelled?
-        fence()
-        complete = all(pg.settle(v) for v in views if v is not None)
-    # the same steps without the collective: what the gather costs end to end
-    state["gather"] = False
+    complete = leg.complete(fence)
+    gather = leg.on
+    leg.on = False   # the same steps without the collective: what the gather costs end to end
     tb_ng = timed_blocks(step, args.steps, 1, fence, first=tb["next"])
     sec_ng = median(tb_ng["per_step_s"])
     kms, _ = kernel_ms(dut, w["step"], args.steps * tb["reps"], tb_ng["next"], fence)
-    gather_ms = None
-    if gather:  # the collective alone, back to back on its stream
-        fence()
-        t0 = time.perf_counter()
-        for k in range(20):
-            pg.gather(lists[k % sets], out=g_lists[k % sets])
-        fence()
-        gather_ms = fence.max_over_ranks(time.perf_counter() - t0) / 20 * 1e3
+    leg.on = gather
+    gather_ms = leg.alone_ms(fence)
     if rank != 0:
         return None
     cells_total = total_ch * nd * nr
@@ -580,12 +673,9 @@ def run_cfg5(args, torch, dist, R, rank, local_rank, world, dev, use_dist, main_
         "config": {"workload": w["name"] + "; RCCL all-gather of the packed lists, one per step, side stream",
                    "cells_per_step_total": cells_total, "channels_per_gpu": n_ch, "buffer_sets": sets,
                    "sharding": "contiguous channels per rank (dist.shard_range); no data-path collective"},
-        "gather": {"ms_per_collective_alone": gather_ms, "ms_per_step_without_gather": sec_ng * 1e3,
-                   "rows_per_rank": pg.rows if gather else None, "bytes_per_rank": pg.rows * 16 if gather else None,
-                   "capacity_rows": cap + 1, "every_timed_list_complete": complete},
+        "gather": leg.report(gather_ms, sec_ng, complete),
         "scaling_note": ("weak scaling: 8 Rx of 8192 x 1024 per GPU at every N (N = 8 is BASELINE.json configs[4]); the 1-GPU point of this "
-                         "curve is the N = 1 line's `scaling_baseline` (= extra.cfg5_share), NOT its headline `value` (configs[1], a lighter "
-                         "workload per cell)"),
+                         "curve is the N = 1 line's `scaling_baseline` (= extra.cfg5_share)"),
         "per_gpu_value": cells_total / sec / world,
         "roofline": roofline(w["kernel"], kms, 28.0 * n_ch * nd * nr, traffic, src),
     }

@@ -417,7 +417,7 @@ __device__ __forceinline__ int wrap16(int x) { return (int)(short)x; }
 // rom[k] = {W1 = {wr, -wi}, W2 = {wi, wr}} (8 bytes; fx_rom_entry).  Bit-identical to pass_fx (same integers).
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ uint2 fx_rom_entry(uint32_t w) {  // w = (wr << 16) | (wi & 0xffff), the global ROM's format
+__host__ __device__ __forceinline__ uint2 fx_rom_entry(uint32_t w) {  // w = (wr << 16) | (wi & 0xffff), the global ROM's first format
   const uint32_t wr = w >> 16, wi = w & 0xffffu;
   return make_uint2((wr << 16) | ((0u - wi) & 0xffffu), (wi << 16) | wr);
 }
@@ -430,9 +430,12 @@ __device__ __forceinline__ uint2 fx_rom_entry(uint32_t w) {  // w = (wr << 16) |
 __host__ __device__ constexpr int fx_rom_slot(int k) { return k + (k >> 4) + (k >> 8); }
 __host__ __device__ constexpr int fx_rom_slots(int M) { return fx_rom_slot((1 << M) / 2) + 1; }
 __host__ __device__ constexpr int fx_rom_bytes(int M) { return 8 * fx_rom_slots(M); }
-// global ROM (N/2 words) -> LDS, by all the workgroup's threads
+// global ROM -> LDS, by all the workgroup's threads.  The global ROM holds N/2 words {wr, wi} (what the small-frame
+// kernel and the stage-option path read) followed by the same N/2 twiddles as fx_rom_entry pairs (rspchain_api.cpp
+// get_rom), so the fill is a copy.
 __device__ __forceinline__ void fx_rom_fill(uint2* rom, const uint32_t* __restrict__ twq, int half, int tid, int nthreads) {
-  for (int i = tid; i < half; i += nthreads) rom[fx_rom_slot(i)] = fx_rom_entry(twq[i]);
+  const uint2* __restrict__ src = reinterpret_cast<const uint2*>(twq + half);
+  for (int i = tid; i < half; i += nthreads) rom[fx_rom_slot(i)] = src[i];
 }
 __device__ __forceinline__ int fx_rom_wr(uint2 e) { return (int)(short)(e.y & 0xffffu); }
 __device__ __forceinline__ int fx_rom_wi(uint2 e) { return (int)(short)(e.y >> 16); }
@@ -731,22 +734,22 @@ template <>
 struct CfarMath<int> {
   static __device__ __forceinline__ int side(int sum, const ChainRegs& rg) { return sum >> rg.div_sum; }
   static __device__ __forceinline__ int half_sum(int a, int b) { return (a + b) >> 1; }
-  // branch-free: both domains computed, selected by the (uniform) logOrLinearMode register.
+  // The domain is the (uniform) logOrLinearMode register: a scalar branch, one domain's arithmetic per cell.
   // Ranges: magnitudes are 16-bit, so cut / thr products below fit 32 bits; stat * scaler needs 64.
   static __device__ __forceinline__ uint32_t finish(int stat, int cut, bool group_ok, int k,
                                                     int log2n, const ChainRegs& rg) {
-    int lin;
-    if (rg.fast32) {  // (uniform) the product is exact in 32 bits: the same integers as the 64-bit form below
+    int thr;
+    if (!rg.linear) {
+      const int lg = ((stat << rg.log_shl) >> rg.log_shr) + rg.log_scaler;
+      thr = min(max(lg, rg.tmin), rg.tmax);
+    } else if (rg.fast32) {  // (uniform) the product is exact in 32 bits: the same integers as the 64-bit form below
       const int l32 = (__mul24(stat, (int)rg.scaler_raw) << rg.lin_shl) >> rg.lin_shr;  // arithmetic: floor, as the spec's trim_shift
-      lin = min(max(l32, rg.tmin), rg.tmax);
+      thr = min(max(l32, rg.tmin), rg.tmax);
     } else {
       const long long prod = ((long long)stat * (long long)rg.scaler_raw) << rg.lin_shl;
       const long long lin64 = prod >> rg.lin_shr;
-      lin = lin64 > (long long)rg.tmax ? rg.tmax : (lin64 < (long long)rg.tmin ? rg.tmin : (int)lin64);
+      thr = lin64 > (long long)rg.tmax ? rg.tmax : (lin64 < (long long)rg.tmin ? rg.tmin : (int)lin64);
     }
-    int lg = ((stat << rg.log_shl) >> rg.log_shr) + rg.log_scaler;
-    lg = min(max(lg, rg.tmin), rg.tmax);
-    const int thr = rg.linear ? lin : lg;
     // cut * 2^bp_thr > thr * 2^bp_in, both sides within 31 bits (16-bit values, shifts <= 15)
     const uint32_t peak = ((cut * (1 << rg.bp_thr)) > (thr * (1 << rg.bp_in))) && group_ok;
     return ((uint32_t)thr << (log2n + 1)) | ((uint32_t)k << 1) | peak;

@@ -368,11 +368,15 @@ int get_rom(rsp_chain* c, int log2n, const void** out) {
     HIP_TRY(hipMemcpy(rom.d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
   } else {
     // Q2.14 (twiddleWidth 16, FftMagCfarChain.scala:80), round to nearest
-    std::vector<uint32_t> h((size_t)half);
+    // N/2 words {wr, wi}, then the same twiddles as the operand pairs the packed butterflies read (fx_rom_entry)
+    std::vector<uint32_t> h((size_t)half * 3);
     for (int k = 0; k < half; ++k) {
       const double a = -2.0 * M_PI * (double)k / (double)n;
       const int wr = (int)std::lround(std::cos(a) * 16384.0), wi = (int)std::lround(std::sin(a) * 16384.0);
       h[k] = ((uint32_t)(wr & 0xFFFF) << 16) | (uint32_t)(wi & 0xFFFF);
+      const uint2 e = rsp::fx_rom_entry(h[k]);
+      h[(size_t)half + 2 * k] = e.x;
+      h[(size_t)half + 2 * k + 1] = e.y;
     }
     HIP_TRY(hipMalloc(&rom.d, h.size() * sizeof(uint32_t)));
     HIP_TRY(hipMemcpy(rom.d, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice));

@@ -73,9 +73,37 @@ def gather_packed(packed, group=None, out=None, async_op: bool = False, rows: in
     return (view, h) if async_op else view
 
 
+def gather_packed_batch(batch, group=None, out=None, stage=None, rows: int = 0):
+    """The lists of K steps in ONE collective: `batch` is an int32 tensor [K, cap + 1, 4], each [cap + 1, 4] slice a
+    packed list as in gather_packed.  A step of tens of microseconds cannot hide a collective of its own (launch
+    latency and the CU share of the RCCL kernel: 12 us per 49-us step, measured); K lists per collective amortise it.
+    The first `rows` rows of every slice are packed into `stage` ([K * rows, 4], allocated if None) and gathered.
+    Returns the gathered [world, K, rows, 4] tensor."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    k = batch.shape[0]
+    rows = min(rows, batch.shape[1]) if rows > 0 else batch.shape[1]
+    if k == 1:   # one list: its first rows are contiguous already
+        stage = batch[0, :rows]
+    else:
+        if stage is None:
+            stage = torch.empty((k * rows, DET_WORDS), dtype=batch.dtype, device=batch.device)
+        else:
+            stage = stage.view(-1, DET_WORDS)[:k * rows]
+        stage.view(k, rows, DET_WORDS).copy_(batch[:, :rows])
+    if out is None:
+        out = torch.empty((world * k * rows, DET_WORDS), dtype=batch.dtype, device=batch.device)
+    else:
+        out = out.view(-1, DET_WORDS)[:world * k * rows]
+    dist.all_gather_into_tensor(out, stage, group=group)
+    return out.view(world, k, rows, DET_WORDS)
+
+
 def gathered_complete(view) -> bool:
     """Did every rank's stored entries fit the rows that were gathered?  (Reads the headers: synchronises.)"""
-    return int(view[:, 0, 1].max().item()) + 1 <= view.shape[1]
+    return int(view[..., 0, 1].max().item()) + 1 <= view.shape[-2]
 
 
 class PackedGatherer:
@@ -83,7 +111,7 @@ class PackedGatherer:
 
     north_star: "RCCL over xGMI used only to gather the final detection list".  A step's list holds `stored`
     entries of a fixed-capacity buffer; the collective carries `rows` rows, rows - 1 >= the largest `stored`
-    seen so far with a 2x margin (a power of two, so that the size changes rarely).  gather() never reads the
+    seen so far with a 25 % margin (a multiple of 1024, so that the size changes rarely).  gather() never reads the
     device; settle() -- off the hot path, e.g. every few steps or when a consumer needs the list -- reads the
     gathered headers, grows `rows` when a list did not fit and says whether the view is complete (a caller
     that needs every step complete repeats the gather of that step with the full capacity)."""
@@ -94,10 +122,14 @@ class PackedGatherer:
     def gather(self, packed, out=None, async_op: bool = False, full: bool = False):
         return gather_packed(packed, self.group, out, async_op, rows=0 if full else self.rows)
 
+    def gather_batch(self, batch, out=None, stage=None, full: bool = False):
+        return gather_packed_batch(batch, self.group, out, stage, rows=0 if full else self.rows)
+
     def settle(self, view) -> bool:
-        need = int(view[:, 0, 1].max().item()) + 1
-        ok = need <= view.shape[1]
-        want = 1 << (2 * need - 1).bit_length()   # the next power of two >= twice the need
+        """view: [world, rows, 4] of gather() or [world, K, rows, 4] of gather_batch()"""
+        need = int(view[..., 0, 1].max().item()) + 1
+        ok = need <= view.shape[-2]
+        want = -(-(need + need // 4) // 1024) * 1024   # 25 % headroom, in steps of 1024 rows
         if want > self.rows:
             self.rows = min(want, self.cap + 1)
         return ok

@@ -75,6 +75,18 @@ WORKER = textwrap.dedent("""
     l3, s3, f3 = unpack_gathered(v)
     m3 = merge_gathered(l3, s3, firsts)
     assert sorted(zip(m3[:, 0].tolist(), m3[:, 1].tolist())) == want
+    # the lists of K steps in one collective: slice j of the batch is the list rotated by j entries
+    K = 3
+    batch = torch.full((K, cap + 1, 4), -9, dtype=torch.int32)
+    for j in range(K):
+        batch[j, 0, 0], batch[j, 0, 1] = k, k
+        batch[j, 1:1 + k] = torch.from_numpy(np.roll(lst[:k], j, axis=0))
+    vb = pg.gather_batch(batch)
+    assert vb.shape == (world, K, pg.rows, 4) and pg.settle(vb)
+    for j in range(K):
+        lj, sj, fj = unpack_gathered(vb[:, j])
+        mj = merge_gathered(lj, sj, firsts)
+        assert sorted(zip(mj[:, 0].tolist(), mj[:, 1].tolist())) == want
     dist.barrier(); dist.destroy_process_group()
     print("rank", rank, "ok", len(want))
 """)

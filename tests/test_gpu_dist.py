@@ -55,6 +55,23 @@ WORKER = textwrap.dedent("""
         merged, w, peaks = check(dut, beats, frames, n, 4096)
         got = sorted((int(a) * n + int(b), int(wd) & 0xffffffff) for a, b, _, wd in merged)
         assert got == [(int(p), int(w[p])) for p in peaks]
+        # the lists of K steps in one collective (bench.py --gpus N, cfg 2): the chain writes step j's list into slot j
+        K, cap = 3, 4096
+        batch = torch.zeros(K, cap + 1, 4, dtype=torch.int32, device=dev)
+        d_in = torch.from_numpy(beats).to(dev)
+        words = torch.empty(frames * n, dtype=torch.int32, device=dev)
+        for j in range(K):   # step j: the first frames - 8 j frames of the batch
+            dut.process_detect_device(d_in.data_ptr(), frames - 8 * j, words.data_ptr(), batch[j][1:].data_ptr(), cap, batch[j][0].data_ptr())
+        pg = PackedGatherer(cap, min_rows=4)
+        vb = pg.gather_batch(batch)
+        if not pg.settle(vb):
+            vb = pg.gather_batch(batch)
+        assert pg.settle(vb) and vb.shape[:2] == (1, K) and vb.shape[2] < cap + 1
+        for j in range(K):
+            lj, sj, fj = unpack_gathered(vb[:, j])
+            mj = merge_gathered(lj, sj, [0])
+            want = [(int(p), int(w[p])) for p in peaks if p < (frames - 8 * j) * n]
+            assert sorted((int(a) * n + int(b), int(wd) & 0xffffffff) for a, b, _, wd in mj) == want, j
     # 2-D chain (the cfg-5 code path of bench.py --gpus N), fp32, list appended by the CFAR kernel
     nr, nd, n_ch = 1024, 256, 2
     p2 = R.FftMagCfarVanillaParameters(fftParams=R.FFTParams.fixed(numPoints=nr), magParams=R.MAGParams.fixed(),

@@ -38,6 +38,6 @@ cd $R
 [ -f ab_ablate.so ] && bash tools/ablate.sh 8192 2048 100 f32 gos > $O/ablate_gos.txt 2>&1
 [ -x tools/valubench ] && timeout -k 5 120 tools/valubench > $O/valubench.txt 2>&1
 cd /tmp
-RSP_BENCH_FORCE_DIST=1 python3 $R/bench.py --steps 8 --warmup 2 > $O/bench_cfg5_1rank_rccl.json 2> $O/bench_cfg5.err
+RSP_BENCH_FORCE_DIST=1 python3 $R/bench.py --steps 20 --warmup 4 > $O/bench_1rank_rccl.json 2> $O/bench_1rank_rccl.err
 python3 $R/tools/pcie_rate.py > $O/pcie.json 2> $O/pcie.err
 echo done

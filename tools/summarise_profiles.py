@@ -8,7 +8,7 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", rnd, "collect"); dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 for a, b in (("bench.json", f"bench_{rnd}.json"), ("bench_under_rocprof.json", f"bench_{rnd}_under_rocprof.json"),
-             ("bench_cfg5_1rank_rccl.json", f"bench_{rnd}_cfg5_1rank_rccl.json"), ("pcie.json", f"pcie_inclusive_{rnd}.json"),
+             ("bench_1rank_rccl.json", f"bench_{rnd}_1rank_rccl.json"), ("pcie.json", f"pcie_inclusive_{rnd}.json"),
              ("ablate.txt", f"ablate_{rnd}.txt"), ("ablate_fx4096.txt", f"ablate_{rnd}_fx4096.txt"),
              ("ablate_gos.txt", f"ablate_{rnd}_gos.txt"), ("valubench.txt", f"valubench_{rnd}.txt")):
     p = os.path.join(src, a)
