@@ -344,7 +344,8 @@ chain1d_gos_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint
   V mg[16];
   SideHooks hk;
   hk.init(rg);
-  front_end<M, FIXED, V, FX>(in, frame, live, tau, fbase, rg, tw, log_lut,
+// (side builds, -DRSP_ABLATE: mask bit 5 reads 64 resident frames instead of the batch, bit 6 drops the word stores)
+  front_end<M, FIXED, V, FX>(in, hk.off(5) ? (frame & 63u) : frame, live, tau, fbase, rg, tw, log_lut,
                              reinterpret_cast<uint2*>(smem + (size_t)lay.frame_bytes * FPW), mg, hk);
 
   // LDS images of the tail, all unpadded (a thread's run of window starts puts its lanes RUN = 17 words apart: odd,
@@ -453,7 +454,7 @@ chain1d_gos_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint
     for (int j = 0; j < 16; ++j) ww.w[j] = word[j];
 #pragma unroll
     for (int e = 0; e < 4; ++e) cc.q[e] = cutq[e];
-    quad_emit<M, V, V4, SideHooks>(ww, cc, tau, frame, live, rg, out, fcount, fdet, det_cnt, det_stage);
+    quad_emit<M, V, V4, SideHooks>(ww, cc, tau, frame, live, rg, hk.off(6) ? nullptr : out, fcount, fdet, det_cnt, det_stage);
   }
 }
 

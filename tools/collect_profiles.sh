@@ -36,6 +36,7 @@ cd $R
 [ -f ab_ablate.so ] && bash tools/ablate.sh > $O/ablate.txt 2>&1
 [ -f ab_ablate.so ] && bash tools/ablate.sh 4096 4096 100 fx16 > $O/ablate_fx4096.txt 2>&1
 [ -f ab_ablate.so ] && bash tools/ablate.sh 8192 2048 100 f32 gos > $O/ablate_gos.txt 2>&1
+[ -f ab_ablate.so ] && bash tools/ablate.sh 8192 2048 100 f32 > $O/ablate_ca8192.txt 2>&1
 [ -x tools/valubench ] && timeout -k 5 120 tools/valubench > $O/valubench.txt 2>&1
 cd /tmp
 RSP_BENCH_FORCE_DIST=1 python3 $R/bench.py --steps 20 --warmup 4 > $O/bench_1rank_rccl.json 2> $O/bench_1rank_rccl.err

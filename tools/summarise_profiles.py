@@ -10,7 +10,7 @@ os.makedirs(dst, exist_ok=True)
 for a, b in (("bench.json", f"bench_{rnd}.json"), ("bench_under_rocprof.json", f"bench_{rnd}_under_rocprof.json"),
              ("bench_1rank_rccl.json", f"bench_{rnd}_1rank_rccl.json"), ("pcie.json", f"pcie_inclusive_{rnd}.json"),
              ("ablate.txt", f"ablate_{rnd}.txt"), ("ablate_fx4096.txt", f"ablate_{rnd}_fx4096.txt"),
-             ("ablate_gos.txt", f"ablate_{rnd}_gos.txt"), ("valubench.txt", f"valubench_{rnd}.txt")):
+             ("ablate_gos.txt", f"ablate_{rnd}_gos.txt"), ("ablate_ca8192.txt", f"ablate_{rnd}_ca8192.txt"), ("valubench.txt", f"valubench_{rnd}.txt")):
     p = os.path.join(src, a)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, b))
