@@ -29,7 +29,6 @@ static hipError_t launch_gos(const Chain1dLaunch& a) {
   const uint32_t grid = (a.n_frames + fpw - 1) / fpw;
   const GosLayout lay = gos_layout<M>(a.regs);
   const size_t lds = (size_t)lay.frame_bytes * fpw + (kPartFixed ? FrameLds<M>::ROM_BYTES : 0);
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
   auto go = [&](auto k, LdsGrant& g) -> hipError_t {
     hipError_t err = grant_lds(k, lds, a.device, g);
     if (err != hipSuccess) return err;
@@ -115,6 +114,7 @@ hipError_t launch_chain1d_part_f32(const Chain1dLaunch& a) {
     case 11: return launch_m<11>(a);
     case 12: return launch_m<12>(a);
     case 13: return launch_m<13>(a);
+    case 14: return launch_m<14>(a);
     default: return hipErrorInvalidValue;
   }
 }

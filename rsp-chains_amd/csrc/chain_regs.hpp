@@ -37,7 +37,8 @@ struct ChainRegs {
 
 constexpr int kMinLog2N = 8;       // LDS-tiled kernels: scan rows are 16 lanes x 16 cells = 256 cells
 constexpr int kMinLog2NSmall = 4;  // one-thread-per-frame kernel (small.hip): 16..128 points
-constexpr int kMaxLog2N = 13;  // 8192 points: 68 KiB LDS per frame
+constexpr int kMaxLog2N = 14;    // 16384 points: one 1024-thread workgroup per CU, 137 KiB of LDS (8192: 68 KiB per frame)
+constexpr int kMaxLog2N2d = 13;  // 2-D chain: range FFT up to 8192 points (tiled intermediate maps)
 constexpr int kMaxRef = 128;   // refWindow + guardWindow <= 256 (LDS prefix halo)
 
 }  // namespace rsp

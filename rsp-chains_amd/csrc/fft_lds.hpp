@@ -45,6 +45,7 @@ __host__ __device__ constexpr int plan_w(int M, int p) {
     case 11: return p < 2 ? 4 : (p == 2 ? 3 : 0);
     case 12: return p < 3 ? 4 : 0;
     case 13: return p == 0 ? 4 : (p < 4 ? 3 : 0);
+    case 14: return p < 2 ? 4 : (p < 4 ? 3 : 0);
     default: return 0;
   }
 }

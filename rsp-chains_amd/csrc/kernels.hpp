@@ -96,6 +96,7 @@ struct LdsGrant {
 };
 template <typename K>
 inline hipError_t grant_lds(K kernel, size_t lds, int device, LdsGrant& granted) {
+  if (lds > 160 * 1024) return hipErrorOutOfMemory;  // more than a CU has: the caller reports the configuration as unsupported
   if (lds <= 48 * 1024) return hipSuccess;  // within the default limit
   if (device < 0 || device >= kMaxDevices) device = kMaxDevices - 1;  // shared slot: still correct, set again
   // benign race between host threads of different handles: both would set the same attribute

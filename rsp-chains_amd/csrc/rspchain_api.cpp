@@ -175,6 +175,8 @@ int validate(const rsp_chain_params* p) {
       return fail(RSP_ERR_UNSUPPORTED, "2-D chain, FIXED16: expandLogic / keepMSBorLSB stage options are defined for the 1-D chain only");
     if (!is_pow2(p->dopplerPoints) || p->dopplerPoints < 256 || p->dopplerPoints > 1024)
       return fail(RSP_ERR_UNSUPPORTED, "dopplerPoints = %d: 256, 512 or 1024", p->dopplerPoints);
+    if (m_max > rsp::kMaxLog2N2d)
+      return fail(RSP_ERR_UNSUPPORTED, "2-D chain: numPoints = %d, the range FFT holds up to %d points", f.numPoints, 1 << rsp::kMaxLog2N2d);
     if (p->refDoppler < 1 || p->guardDoppler < 0 || p->refDoppler + p->guardDoppler > 32)
       return fail(RSP_ERR_INVALID, "refDoppler/guardDoppler = %d/%d", p->refDoppler, p->guardDoppler);
     if (c.sendCut || !f.useBitReverse)
@@ -488,7 +490,12 @@ int launch_frames(rsp_chain* c, const void* d_in, size_t n_frames, uint32_t* d_o
     a.ev_stop = c->prof_events[c->prof_used].second;
     ++c->prof_used;
   }
-  HIP_TRY(rsp::launch_chain1d(a));
+  const hipError_t le = rsp::launch_chain1d(a);
+  if (le == hipErrorOutOfMemory)
+    return fail(RSP_ERR_UNSUPPORTED, "%d-point frames: this CFAR configuration needs more than the 160 KiB of LDS of a workgroup "
+                "(16384 points hold CA / GO / SO with window sizes that are multiples of 4, and the fp32 ordered statistic with "
+                "indexLagg = indexLead)", 1 << a.log2n);
+  HIP_TRY(le);
   return RSP_OK;
 }
 

@@ -16,7 +16,7 @@ def run_fixed(params, rt, beats):
         return dut.stream(beats)
 
 
-@pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, 8192])
+@pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, 8192, 16384])
 def test_fixed_bit_exact_all_sizes(gpu, n):
     params = make_params(n)
     rt = R.RunTimeRspChainParams(fftSize=n)
@@ -206,7 +206,7 @@ def test_detection_list_is_complete_beyond_the_per_frame_staging(gpu):
         assert np.array_equal(np.bincount(lst[:, 0], minlength=frames), np.minimum(per_frame, 64))
 
 
-@pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, 8192])
+@pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, 8192, 16384])
 def test_f32_all_sizes(gpu, n):
     params = make_params(n, dtype=R.F32, leadLagg=64)
     rt = R.RunTimeRspChainParams(fftSize=n, CFARMode="Cell Averaging")
@@ -305,7 +305,7 @@ def test_gosca_runtime_algorithm_select(gpu):
         assert np.array_equal(got, O.chain_fixed(beats, oracle_cfg(params, rt)).reshape(got.shape)), alg
 
 
-@pytest.mark.parametrize("n,ref,idx", [(8192, 32, 24), (2048, 16, 12)])
+@pytest.mark.parametrize("n,ref,idx", [(8192, 32, 24), (2048, 16, 12), (16384, 32, 24), (16384, 64, 40)])
 def test_f32_gos(gpu, n, ref, idx):
     """BASELINE.json configs[3]: OS-CFAR, 32-cell window, 8192-point spectrum (k = 3R/4, G = 4)."""
     params = make_params(n, dtype=R.F32, alg=R.GOSCFARType)
@@ -439,3 +439,35 @@ def test_fused_list_order_and_large_frame_counts(gpu, frames):
         assert np.array_equal(np.sort(key), fr.astype(np.int64) * n + bn)
     assert np.array_equal(np.sort(key), fr.astype(np.int64) * n + bn)
     assert np.array_equal(lst[np.argsort(key), 3], dense[fr, bn])
+
+
+def test_16384_point_frames(gpu):
+    """numPoints = 16384 (FFTParams.fixed accepts any power of two: FftMagCfarChain.scala:78-90): one 1024-thread workgroup
+    per frame, 137 KiB of LDS.  CA / GO / SO on the quad tail in both data types (sizes above), a smaller run-time
+    fftSize on the same object, the wide beat; what does not fit the 160 KiB says so instead of failing in the launch."""
+    n = 16384
+    params = make_params(n, guard=8)
+    for mode, size in (("Greatest Of", n), ("Smallest Of", n), ("Cell Averaging", 2048)):
+        rt = R.RunTimeRspChainParams(fftSize=size, CFARMode=mode, refWindowSize=32, guardWindowSize=8, divSum=5,
+                                     thresholdScaler=2.0, peakGrouping=1)
+        beats = np.concatenate([tone_beats(2, size, 77), random_beats(3, size, 78)])
+        got = run_fixed(params, rt, beats)
+        assert np.array_equal(got, O.chain_fixed(beats, oracle_cfg(params, rt)).reshape(got.shape)), mode
+    wide = make_params(n, sendCut=True, guard=8)
+    rt = R.RunTimeRspChainParams(fftSize=n, refWindowSize=16, guardWindowSize=4, divSum=4)
+    beats = random_beats(3, n, 79)
+    got = run_fixed(wide, rt, beats)
+    assert np.array_equal(got, O.chain_fixed(beats, oracle_cfg(wide, rt)).reshape(got.shape))
+    # per-cell tail (window sizes that are not multiples of 4) + FIXED16 twiddle ROM: 215 KiB
+    odd = R.RunTimeRspChainParams(fftSize=n, refWindowSize=8, guardWindowSize=3, divSum=3)
+    with R.FftMagCfarChainVanilla(params) as dut:
+        dut.configure(odd)
+        with pytest.raises(NotImplementedError, match="160 KiB"):
+            dut.stream(beats)
+        dut.configure(rt)                               # the object is still usable
+        assert dut.stream(beats).shape == (3, n)
+    # the 2-D chain keeps its 8192-point range FFT
+    with pytest.raises(NotImplementedError, match="range FFT holds up to 8192"):
+        R.FftMagCfarChainVanilla(R.FftMagCfarVanillaParameters(
+            fftParams=R.FFTParams.fixed(numPoints=n), magParams=R.MAGParams.fixed(),
+            cfarParams=R.CFARParams(fftSize=n, leadLaggWindowSize=16), dtype=R.F32, dopplerPoints=256, refDoppler=8, guardDoppler=2))
