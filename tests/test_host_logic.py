@@ -26,7 +26,9 @@ def test_reference_parameter_sets_validate():
 @pytest.mark.parametrize("mutate,code", [
     (lambda p: setattr(p.fftParams, "numPoints", 1000), N.RSP_ERR_INVALID),
     (lambda p: (setattr(p.fftParams, "numPoints", 8), setattr(p.cfarParams, "fftSize", 8)), N.RSP_ERR_UNSUPPORTED),
-    (lambda p: setattr(p.fftParams, "numPoints", 16384), N.RSP_ERR_UNSUPPORTED),
+    (lambda p: (setattr(p.fftParams, "numPoints", 32768), setattr(p.cfarParams, "fftSize", 32768)), N.RSP_ERR_UNSUPPORTED),
+    (lambda p: (setattr(p.fftParams, "numPoints", 16384), setattr(p.cfarParams, "fftSize", 16384), setattr(p, "dopplerPoints", 256),
+                setattr(p, "refDoppler", 4), setattr(p, "dtype", R.F32)), N.RSP_ERR_UNSUPPORTED),
     (lambda p: setattr(p.fftParams, "dataWidth", 18), N.RSP_ERR_UNSUPPORTED),
     (lambda p: setattr(p.fftParams, "expandLogic", [2] * 10), N.RSP_ERR_INVALID),
     (lambda p: (setattr(p.fftParams, "expandLogic", [1] * 10), setattr(p, "dtype", R.F32)), N.RSP_ERR_INVALID),
