@@ -317,6 +317,42 @@ __device__ __forceinline__ void fft_f32_load(Load load, int tau, const f32x2* __
   for (int e = 0; e < 16; ++e) x[e] = load(elem_index<M, LO, W>(0, e) - elem_index<M, LO, W>(0, 0));
 }
 
+// The 16 reads of an exchange as ds_read_b64.  Left to itself the compiler pairs neighbouring 8-byte reads into
+// ds_read2_b64, which the LDS serves at HALF the rate per byte (tools/valubench.hip, four waves per SIMD: ds_read_b64
+// 6.2 ticks per 512 B, ds_read2_b64 24.1 per 1024 B; MI355X_MICROARCH.md: 256 B/clk on 64 banks vs 128 B/clk on 32), and
+// a volatile access does not stop it.  Two asm blocks of eight reads with immediate offsets; the second ends with the
+// wait for all sixteen and carries the first eight as in/out operands, so nothing can touch a register before its data
+// has arrived (the compiler does not count LDS operations issued by inline asm).
+typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
+template <int M, int LO, int W, bool LAST, int H>
+__device__ __forceinline__ void lds_read8_b64(int tau, const f32x2* buf, f32x2 (&x)[16]) {
+  static_assert(W == 3 || W == 4, "field widths of the plans");
+  constexpr int G = W == 4 ? 0 : H, R0 = W == 4 ? 8 * H : 0, E = 8 * H;
+  const uint32_t a = (uint32_t)(uintptr_t)(const lds_byte_t*)(buf + slot_base<M, LO, W, LAST>(tau, G));
+#define RSP_OFF(j) "n"(8 * slot_delta<M, LO, W>(R0 + j))
+  if constexpr (H == 0) {
+    asm volatile("ds_read_b64 %0, %8 offset:%9\n\tds_read_b64 %1, %8 offset:%10\n\tds_read_b64 %2, %8 offset:%11\n\t"
+                 "ds_read_b64 %3, %8 offset:%12\n\tds_read_b64 %4, %8 offset:%13\n\tds_read_b64 %5, %8 offset:%14\n\t"
+                 "ds_read_b64 %6, %8 offset:%15\n\tds_read_b64 %7, %8 offset:%16"
+                 : "=&v"(x[E]), "=&v"(x[E + 1]), "=&v"(x[E + 2]), "=&v"(x[E + 3]), "=&v"(x[E + 4]), "=&v"(x[E + 5]), "=&v"(x[E + 6]),
+                   "=&v"(x[E + 7])
+                 : "v"(a), RSP_OFF(0), RSP_OFF(1), RSP_OFF(2), RSP_OFF(3), RSP_OFF(4), RSP_OFF(5), RSP_OFF(6), RSP_OFF(7)
+                 : "memory");
+  } else {
+    asm volatile("ds_read_b64 %0, %16 offset:%17\n\tds_read_b64 %1, %16 offset:%18\n\tds_read_b64 %2, %16 offset:%19\n\t"
+                 "ds_read_b64 %3, %16 offset:%20\n\tds_read_b64 %4, %16 offset:%21\n\tds_read_b64 %5, %16 offset:%22\n\t"
+                 "ds_read_b64 %6, %16 offset:%23\n\tds_read_b64 %7, %16 offset:%24\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(x[E]), "=&v"(x[E + 1]), "=&v"(x[E + 2]), "=&v"(x[E + 3]), "=&v"(x[E + 4]), "=&v"(x[E + 5]), "=&v"(x[E + 6]),
+                   "=&v"(x[E + 7]), "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])
+                 : "v"(a), RSP_OFF(0), RSP_OFF(1), RSP_OFF(2), RSP_OFF(3), RSP_OFF(4), RSP_OFF(5), RSP_OFF(6), RSP_OFF(7)
+                 : "memory");
+  }
+#undef RSP_OFF
+}
+// the largest immediate an exchange read needs (ds offsets are 16 bits)
+template <int M, int LO, int W>
+__host__ __device__ constexpr int lds_read_max_off() { return 8 * slot_delta<M, LO, W>((1 << W) - 1); }
+
 // one exchange through the LDS image + the register pass behind it
 template <int M, int P, typename Hooks>
 __device__ __forceinline__ void fft_f32_exchange(int tau, f32x2* buf, const TwAll<M>& twb, f32x2 (&x)[16], Hooks& hk) {
@@ -336,11 +372,20 @@ __device__ __forceinline__ void fft_f32_exchange(int tau, f32x2* buf, const TwAl
   Hooks::barrier();
   hk.template after_exchange_barrier<P>();
   if (!hk.off(3)) {
+#ifdef RSP_EXCHANGE_READ2   // (side builds) the compiler's pairing, for A/B runs
+    if constexpr (false) {
+#else
+    if constexpr (lds_read_max_off<M, LO1, W1>() < 65536) {
+#endif
+      lds_read8_b64<M, LO1, W1, LAST, 0>(tau, buf, x);
+      lds_read8_b64<M, LO1, W1, LAST, 1>(tau, buf, x);
+    } else {
 #pragma unroll
-    for (int g = 0; g < (16 >> W1); ++g) {
-      const f32x2* b1 = buf + slot_base<M, LO1, W1, LAST>(tau, g);
+      for (int g = 0; g < (16 >> W1); ++g) {
+        const f32x2* b1 = buf + slot_base<M, LO1, W1, LAST>(tau, g);
 #pragma unroll
-      for (int r = 0; r < (1 << W1); ++r) x[g * (1 << W1) + r] = b1[slot_delta<M, LO1, W1>(r)];
+        for (int r = 0; r < (1 << W1); ++r) x[g * (1 << W1) + r] = b1[slot_delta<M, LO1, W1>(r)];
+      }
     }
   }
   hk.stamp(2 * P + 1);

@@ -175,6 +175,18 @@ __global__ void __launch_bounds__(1024) bench(unsigned long long* out, float* si
     } else if constexpr (KIND == 59) {  // v_min3_f32
       REP8(asm volatile("v_min3_f32 %0, %0, %8, %9\n v_min3_f32 %1, %1, %8, %9\n v_min3_f32 %2, %2, %8, %9\n v_min3_f32 %3, %3, %8, %9\n v_min3_f32 %4, %4, %8, %9\n v_min3_f32 %5, %5, %8, %9\n v_min3_f32 %6, %6, %8, %9\n v_min3_f32 %7, %7, %8, %9"
                         : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]) : "v"(b.x), "v"(c.x));)
+    } else if constexpr (KIND == 60) {  // ds_read2_b64: two 8-byte reads per lane and instruction
+      f32x2 a2[8];
+      REP8(asm volatile("ds_read2_b64 %0, %8 offset1:32\n ds_read2_b64 %1, %8 offset0:64 offset1:96\n ds_read2_b64 %2, %8 offset0:128 offset1:160\n ds_read2_b64 %3, %8 offset0:192 offset1:224\n s_waitcnt lgkmcnt(0)"
+                        : "=v"(*(float __attribute__((ext_vector_type(4)))*)&a[0]), "=v"(*(float __attribute__((ext_vector_type(4)))*)&a[2]), "=v"(*(float __attribute__((ext_vector_type(4)))*)&a[4]), "=v"(*(float __attribute__((ext_vector_type(4)))*)&a[6]),
+                          "=v"(a2[0]), "=v"(a2[1]), "=v"(a2[2]), "=v"(a2[3]) : "v"((unsigned)(threadIdx.x & 255) * 8u) : "memory");)
+    } else if constexpr (KIND == 61) {  // ds_read_b128, lane-contiguous
+      REP8(asm volatile("ds_read_b128 %0, %8\n ds_read_b128 %1, %8 offset:4096\n ds_read_b128 %2, %8 offset:8192\n ds_read_b128 %3, %8 offset:12288\n s_waitcnt lgkmcnt(0)"
+                        : "=v"(*(float __attribute__((ext_vector_type(4)))*)&a[0]), "=v"(*(float __attribute__((ext_vector_type(4)))*)&a[2]), "=v"(*(float __attribute__((ext_vector_type(4)))*)&a[4]), "=v"(*(float __attribute__((ext_vector_type(4)))*)&a[6]),
+                          "=v"(s[0]), "=v"(s[1]), "=v"(s[2]), "=v"(s[3]) : "v"((unsigned)(threadIdx.x & 255) * 16u) : "memory");)
+    } else if constexpr (KIND == 62) {  // ds_write_b128, lane-contiguous
+      REP8(asm volatile("ds_write_b128 %0, %1\n ds_write_b128 %0, %2 offset:4096\n ds_write_b128 %0, %3 offset:8192\n ds_write_b128 %0, %4 offset:12288\n s_waitcnt lgkmcnt(0)"
+                        :: "v"((unsigned)(threadIdx.x & 255) * 16u), "v"(*(float __attribute__((ext_vector_type(4)))*)&a[0]), "v"(*(float __attribute__((ext_vector_type(4)))*)&a[2]), "v"(*(float __attribute__((ext_vector_type(4)))*)&a[4]), "v"(*(float __attribute__((ext_vector_type(4)))*)&a[6]) : "memory");)
     } else if constexpr (KIND == 5) {  // ds_write_b64, lane-contiguous
       REP8(asm volatile("ds_write_b64 %0, %1\n ds_write_b64 %0, %2 offset:2048\n ds_write_b64 %0, %3 offset:4096\n ds_write_b64 %0, %4 offset:6144\n"
                         "ds_write_b64 %0, %5 offset:8192\n ds_write_b64 %0, %6 offset:10240\n ds_write_b64 %0, %7 offset:12288\n ds_write_b64 %0, %8 offset:14336\n s_waitcnt lgkmcnt(0)"
@@ -258,5 +270,6 @@ int main() {
   run<57>("v_lshl_add_u32", 64);
   run<58>("v_med3_i32", 64);
   run<59>("v_min3_f32", 64);
+  run<60>("ds_read2_b64 (4 + wait)", 32); run<61>("ds_read_b128 (4 + wait)", 32); run<62>("ds_write_b128 (4 + wait)", 32);
   return 0;
 }
