@@ -131,8 +131,8 @@ __device__ __forceinline__ void quad_emit(const QuadWords word, const QuadCuts<V
       const V c0 = cutq[e][0], c1 = cutq[e][1], c2 = cutq[e][2], c3 = cutq[e][3];
       const u32x4 lo4 = {word[4 * e], bits_of(c0), word[4 * e + 1], bits_of(c1)};
       const u32x4 hi4 = {word[4 * e + 2], bits_of(c2), word[4 * e + 3], bits_of(c3)};
-      *reinterpret_cast<u32x4*>(obase + (size_t)(32 * T * e)) = lo4;
-      *reinterpret_cast<u32x4*>(obase + (size_t)(32 * T * e) + 16) = hi4;
+      stream_store(lo4, reinterpret_cast<u32x4*>(obase + (size_t)(32 * T * e)));
+      stream_store(hi4, reinterpret_cast<u32x4*>(obase + (size_t)(32 * T * e) + 16));
     }
   } else if (live && out) {
     char* obase = reinterpret_cast<char*>(out);
@@ -140,7 +140,7 @@ __device__ __forceinline__ void quad_emit(const QuadWords word, const QuadCuts<V
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const u32x4 w4 = {word[4 * e], word[4 * e + 1], word[4 * e + 2], word[4 * e + 3]};
-      *reinterpret_cast<u32x4*>(obase + (size_t)ooff + (size_t)(16 * T * e)) = w4;
+      stream_store(w4, reinterpret_cast<u32x4*>(obase + (size_t)ooff + (size_t)(16 * T * e)));
     }
   }
   if (!kCountPath && fcount) {

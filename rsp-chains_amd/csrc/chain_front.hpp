@@ -136,7 +136,7 @@ __device__ __forceinline__ void front_end(const void* __restrict__ in, uint32_t 
     f32x2 x[16];
     TwAll<M> twb;
     const uint32_t voff = ((live ? frame : 0u) * (uint32_t)N + (uint32_t)elem_index<M, LO, W>(tau, 0)) * 8u;
-    fft_f32_load<M>([&](int d) { return *reinterpret_cast<const f32x2*>(gbase + (size_t)voff + (size_t)d * 8u); },
+    fft_f32_load<M>([&](int d) { return stream_load(reinterpret_cast<const f32x2*>(gbase + (size_t)voff + (size_t)d * 8u)); },
                     tau, reinterpret_cast<const f32x2*>(tw), twb, x);
     if (rg.window) {  // pre-FFT window (build extension): one fp32 coefficient per sample
       const float* wt = reinterpret_cast<const float*>(rg.window) + elem_index<M, LO, W>(tau, 0);
@@ -157,7 +157,7 @@ __device__ __forceinline__ void front_end(const void* __restrict__ in, uint32_t 
       for (int e = 0; e < 16; ++e) {
         // beat = {re[31:16], im[15:0]}: RspChainTesterUtils.scala:105-109
         const size_t eo = (size_t)sample_offset<M>(e) * 4u;
-        const uint32_t b = *reinterpret_cast<const uint32_t*>(gbase + (size_t)voff + eo);
+        const uint32_t b = stream_load(reinterpret_cast<const uint32_t*>(gbase + (size_t)voff + eo));
         xr[e] = (int)(short)(b >> 16);
         xi[e] = (int)(short)(b & 0xffffu);
       }
@@ -226,13 +226,16 @@ __device__ __forceinline__ void emit_words(const uint32_t (&word)[16], uint32_t*
   if (live && out && cut_lds) {  // sendCut = true: 64-bit beat {word, cut}; cut of cell tau + T j at cut_lds[cut_stride j]
     uint2* obase = reinterpret_cast<uint2*>(out) + (size_t)frame * N + tau;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) obase[T * j] = make_uint2(word[j], __builtin_bit_cast(uint32_t, cut_lds[cut_stride * j]));
+    for (int j = 0; j < 16; ++j) {
+      const u32x2 beat = {word[j], __builtin_bit_cast(uint32_t, cut_lds[cut_stride * j])};
+      stream_store(beat, reinterpret_cast<u32x2*>(obase + T * j));
+    }
   } else if (live && out) {
     char* obase = reinterpret_cast<char*>(out);
     const uint32_t ooff = (frame * (uint32_t)N + (uint32_t)tau) * 4u;
 #pragma unroll
     for (int j = 0; j < 16; ++j)
-      *reinterpret_cast<uint32_t*>(obase + (size_t)ooff + (size_t)(T * j) * 4u) = word[j];
+      stream_store(word[j], reinterpret_cast<uint32_t*>(obase + (size_t)ooff + (size_t)(T * j) * 4u));
   }
   if (!kCountPath && fcount) {
     uint32_t hits = 0;
@@ -264,6 +267,5 @@ __device__ __forceinline__ uint32_t bits_of(int v) { return (uint32_t)v; }
 template <typename V> struct Vec4;
 template <> struct Vec4<float> { typedef float type __attribute__((ext_vector_type(4))); };
 template <> struct Vec4<int> { typedef int type __attribute__((ext_vector_type(4))); };
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 }  // namespace rsp

@@ -57,6 +57,26 @@ static inline uint32_t rd_tile(int log2nr) {
 }
 
 // ---------------------------------------------------------------- range pass (rows)
+// Streaming hints of the 2-D chain, one bit per access kind (side builds A/B them: tools/build_variant_rd.sh x.so
+// -DRSP_RD_NT=mask): 1 range-pass loads, 2 its spectrum stores, 4 Doppler-pass loads, 8 its magnitude stores,
+// 16 the walker's row loads.  Measured at 8 x 4096 x 512 (base 119-120 us per batch): 1 -> 115-116, 2 -> 129, 4 -> 116-118,
+// 8 -> 119, 16 -> 120-121, the walker's word stores (its own run-time switch, below) -> 113.6-114.5; the gains do not add
+// (1 + 4 + words: 114.0), and at 8 x 8192 x 1024 every one of them is neutral or slower -- the product keeps only the
+// word stores' hint, per launch.
+#ifndef RSP_RD_NT
+#define RSP_RD_NT 0
+#endif
+template <int BIT, typename T>
+__device__ __forceinline__ T rd_load(const T* p) {
+  if constexpr (((RSP_RD_NT) & BIT) != 0) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <int BIT, typename T>
+__device__ __forceinline__ void rd_store(T v, T* p) {
+  if constexpr (((RSP_RD_NT) & BIT) != 0) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
 // TILED is a template parameter: with the row-major layout the 16 stores of a thread are base + compile-time offsets
 // again (a run-time element step cost 7 us of address arithmetic per 16.7 M cells)
 template <int M, bool TILED>
@@ -78,9 +98,9 @@ range_fft_kernel(const f32x2* __restrict__ in, f32x2* __restrict__ out, uint32_t
   f32x2 x[16];
   if (win) {  // fast-time window (build extension)
     const float* wsrc = win + first_sample<M>(tau);
-    fft_f32_frame<M>([&](int d) { const float wv = wsrc[d]; return src[d] * f32x2{wv, wv}; }, tau, buf, tw, x);
+    fft_f32_frame<M>([&](int d) { const float wv = wsrc[d]; return rd_load<1>(src + d) * f32x2{wv, wv}; }, tau, buf, tw, x);
   } else {
-    fft_f32_frame<M>([&](int d) { return src[d]; }, tau, buf, tw, x);
+    fft_f32_frame<M>([&](int d) { return rd_load<1>(src + d); }, tau, buf, tw, x);
   }
   // register (g, p) holds bin (bitrev(p) << (M - WL)) | (g T + tau) (fft_lds.hpp, last pass): consecutive lanes hold
   // consecutive bins, so the spectrum goes straight to HBM in natural order, 512 B per wave-instruction
@@ -95,7 +115,7 @@ range_fft_kernel(const f32x2* __restrict__ in, f32x2* __restrict__ out, uint32_t
 #pragma unroll
     for (int g = 0; g < (16 >> WL); ++g) {
 #pragma unroll
-      for (int p = 0; p < (1 << WL); ++p) dst[(bitrev_c(p, WL) << (M - WL)) + g * T] = x[g * (1 << WL) + p] * scale;
+      for (int p = 0; p < (1 << WL); ++p) rd_store<2>(x[g * (1 << WL) + p] * scale, dst + ((bitrev_c(p, WL) << (M - WL)) + g * T));
     }
   } else {
     // bins c + tau with c a multiple of T >= 16: the tile index splits into a per-lane and a per-register part
@@ -106,7 +126,7 @@ range_fft_kernel(const f32x2* __restrict__ in, f32x2* __restrict__ out, uint32_t
     for (int g = 0; g < (16 >> WL); ++g) {
 #pragma unroll
       for (int p = 0; p < (1 << WL); ++p)
-        dst[(size_t)((bitrev_c(p, WL) << (M - WL)) + g * T) << log2nd] = x[g * (1 << WL) + p] * scale;
+        rd_store<2>(x[g * (1 << WL) + p] * scale, dst + ((size_t)((bitrev_c(p, WL) << (M - WL)) + g * T) << log2nd));
     }
   }
 }
@@ -153,12 +173,12 @@ doppler_mag_kernel(const f32x2* __restrict__ in, float* __restrict__ mag, uint32
   f32x2 x[16];
   if (win) {  // slow-time window
     const float* wsrc = win + first_sample<MD>(tau);
-    fft_f32_frame<MD>([&](int d) { const float wv = wsrc[d]; return src[(size_t)d * pitch] * f32x2{wv, wv}; }, tau, buf, tw, x);
+    fft_f32_frame<MD>([&](int d) { const float wv = wsrc[d]; return rd_load<4>(src + (size_t)d * pitch) * f32x2{wv, wv}; }, tau, buf, tw, x);
   } else {
 #ifdef RSP_ABL_DOP_L2  // ablation builds: rows 0..15 only (L2-resident source)
     fft_f32_frame<MD>([&](int d) { return src[(size_t)(d & 15) * pitch]; }, tau, buf, tw, x);
 #else
-    fft_f32_frame<MD>([&](int d) { return src[(size_t)d * pitch]; }, tau, buf, tw, x);
+    fft_f32_frame<MD>([&](int d) { return rd_load<4>(src + (size_t)d * pitch); }, tau, buf, tw, x);
 #endif
   }
   constexpr int NP = plan_np(MD), WL = plan_w(MD, NP - 1);
@@ -172,7 +192,7 @@ doppler_mag_kernel(const f32x2* __restrict__ in, float* __restrict__ mag, uint32
   for (int g = 0; g < (16 >> WL); ++g) {
 #pragma unroll
     for (int p = 0; p < (1 << WL); ++p)
-      dst[(size_t)bin_of<MD>(tau, g, p) * mpitch] = mag2d(x[g * (1 << WL) + p] * scale, mag_mode);
+      rd_store<8>(mag2d(x[g * (1 << WL) + p] * scale, mag_mode), dst + (size_t)bin_of<MD>(tau, g, p) * mpitch);
   }
 }
 
@@ -205,7 +225,7 @@ doppler_mag_pair_kernel(const f32x2* __restrict__ in, float* __restrict__ mag, u
   {
     const f32x2* src = in + col + (size_t)s0 * pitch;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) raw[e] = *reinterpret_cast<const f32x4*>(src + (size_t)sample_offset<MD>(e) * pitch);
+    for (int e = 0; e < 16; ++e) raw[e] = rd_load<4>(reinterpret_cast<const f32x4*>(src + (size_t)sample_offset<MD>(e) * pitch));
     if (win) {  // slow-time window: one coefficient per row, the same for both columns
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -235,7 +255,7 @@ doppler_mag_pair_kernel(const f32x2* __restrict__ in, float* __restrict__ mag, u
 #pragma unroll
     for (int p = 0; p < (1 << WL); ++p) {
       const int e = g * (1 << WL) + p;
-      *reinterpret_cast<f32x2*>(dst + (size_t)bin_of<MD>(tau, g, p) * mpitch) = f32x2{m0[e], mag2d(x[e] * scale, mag_mode)};
+      rd_store<8>(f32x2{m0[e], mag2d(x[e] * scale, mag_mode)}, reinterpret_cast<f32x2*>(dst + (size_t)bin_of<MD>(tau, g, p) * mpitch));
     }
   }
 }
@@ -537,8 +557,6 @@ template <int CTRL, int ROWMASK, bool BOUND>
 __device__ __forceinline__ float dpp_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, BOUND));
 }
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // Row-direction sums of a lane pair's column values v = (column 2l, column 2l + 1), H even:
 //   box = (sum of columns c - H .. c + H) for c = 2l and 2l + 1,  lag = (sum of columns c - H .. c - 1)
@@ -635,7 +653,7 @@ __global__ void __launch_bounds__(256)
 cfar2d_walk_kernel(const S* __restrict__ mag, uint32_t* __restrict__ out, uint32_t nd, uint32_t nr,
                    uint32_t strips, int edge, float kA, float kB,
                    rsp_detection* __restrict__ det_list, uint32_t det_cap, uint32_t* __restrict__ det_count, uint32_t ch_base,
-                   uint32_t tile, ChainRegs rg, int log2nr) {
+                   uint32_t tile, ChainRegs rg, int log2nr, uint32_t stream_words) {
   typedef typename Pair<S>::type S2;
   constexpr bool FX = !std::is_same<S, float>::value;  // FIXED16 magnitudes: integer sums, thresholds through CfarMath<int>
   constexpr int HR = RR + GR, HD = RD + GD, SPAN = 2 * HD + 2, RING = kWalkRing;
@@ -678,7 +696,7 @@ cfar2d_walk_kernel(const S* __restrict__ mag, uint32_t* __restrict__ out, uint32
 #else
     const uint32_t d = (uint32_t)((up ? d0 + SEG - 1 + HD - p : d0 - HD + p) & ((int)nd - 1));
 #endif
-    return __builtin_bit_cast(S2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_in, voff_in, d * row_bytes, 0));
+    return __builtin_bit_cast(S2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_in, voff_in, d * row_bytes, ((RSP_RD_NT) & 16) ? 2 : 0));  // aux bit 1 = nt
   };
   // fused detection list: peaks are staged in a wave-private LDS buffer during the walk (LDS atomics
   // only: a vector-memory atomic inside the walk, even in a never-taken branch, makes the wait-count
@@ -758,7 +776,11 @@ cfar2d_walk_kernel(const S* __restrict__ mag, uint32_t* __restrict__ out, uint32
         wd.y = (__float_as_uint(t1) & ~1u) | (uint32_t)(cut.y > t1);
       }
       const uint32_t d_out = (uint32_t)(up ? d0 + SEG - 1 - i : d0 + i);
-      __builtin_amdgcn_raw_buffer_store_b64(wd, rsrc_out, voff_out, d_out * nr * 4u, 0);
+      // stream_words (wave-uniform): the words leave with the non-temporal hint, so that they do not push the launch's
+      // intermediate maps out of the Infinity Cache -- 119-120 -> 113.6-114.5 us at 8 x 4096 x 512 (201 MB of maps), but
+      // 522-531 -> 545 us at 8 x 8192 x 1024 (805 MB: nothing to protect), hence per launch (rd_stream_words())
+      if (stream_words) __builtin_amdgcn_raw_buffer_store_b64(wd, rsrc_out, voff_out, d_out * nr * 4u, 2);  // aux bit 1 = nt
+      else __builtin_amdgcn_raw_buffer_store_b64(wd, rsrc_out, voff_out, d_out * nr * 4u, 0);
       if ((wd.x | wd.y) & det_mask) {  // rare
         if (wd.x & 1u) {
           const uint32_t sl = atomicAdd(&stage_cnt[w], 1u);
@@ -832,6 +854,12 @@ cfar2d_walk_kernel(const S* __restrict__ mag, uint32_t* __restrict__ out, uint32
 }
 
 // ---------------------------------------------------------------- launchers
+// the walker's word stores carry the streaming hint when the launch's intermediate maps (spectrum + magnitudes,
+// bytes_per_cell of them) fit the 256-MiB Infinity Cache with room to spare
+static uint32_t rd_stream_words(uint32_t n_ch, uint32_t nd, uint32_t nr, uint32_t bytes_per_cell) {
+  return (uint64_t)n_ch * nd * nr * bytes_per_cell <= (uint64_t)224 << 20 ? 1u : 0u;
+}
+
 
 template <int M>
 static hipError_t launch_range_m(const f32x2* in, f32x2* out, uint32_t n_rows, int log2nd, uint32_t tile, const f32x2* tw, const float* win, uint32_t* zero_count,
@@ -927,7 +955,8 @@ static hipError_t launch_rd2d_chunk(const Rd2dLaunch& a, uint32_t ch0, uint32_t 
     const dim3 grid(n_ch * strips * (nd / SEG / 4));
 #define RSP_WALK(MODE)                                                                                              \
   hipLaunchKernelGGL((cfar2d_walk_kernel<8, 2, 8, 2, SEG, MODE>), grid, dim3(256), 0, a.stream, a.scratch_mag, out, \
-                     nd, nr, strips, a.regs.edge, kA, kB, det_list, det_cap, a.det_count, ch0, tile, a.regs, a.log2nr)
+                     nd, nr, strips, a.regs.edge, kA, kB, det_list, det_cap, a.det_count, ch0, tile, a.regs, a.log2nr, \
+                     rd_stream_words(n_ch, nd, nr, 12))
     if (a.regs.cfar_mode == 0) RSP_WALK(0);
     else if (a.regs.cfar_mode == 1) RSP_WALK(1);
     else RSP_WALK(2);
@@ -1022,7 +1051,8 @@ static hipError_t launch_rd2d_chunk_fx(const Rd2dLaunch& a, uint32_t ch0, uint32
     const dim3 grid(n_ch * strips * (nd / SEG / 4));
 #define RSP_WALK(MODE)                                                                                                   \
   hipLaunchKernelGGL((cfar2d_walk_kernel<8, 2, 8, 2, SEG, MODE, int32_t>), grid, dim3(256), 0, a.stream, mag, out, nd, nr, \
-                     strips, a.regs.edge, 0.f, 0.f, det_list, det_cap, a.det_count, ch0, tile, a.regs, a.log2nr)
+                     strips, a.regs.edge, 0.f, 0.f, det_list, det_cap, a.det_count, ch0, tile, a.regs, a.log2nr, \
+                     rd_stream_words(n_ch, nd, nr, 8))
     if (a.regs.cfar_mode == 0) RSP_WALK(0);
     else if (a.regs.cfar_mode == 1) RSP_WALK(1);
     else RSP_WALK(2);
