@@ -157,18 +157,45 @@ __device__ __forceinline__ void front_end(const void* __restrict__ in, uint32_t 
     magnitudes_f32<M>(x, rg.mag_mode, mg, hk);
   } else {
     const uint32_t* twq = reinterpret_cast<const uint32_t*>(tw);
-    int xr[16], xi[16];
-    {
-      const uint32_t voff = ((live ? frame : 0u) * (uint32_t)N + (uint32_t)elem_index<M, LO, W>(tau, 0)) * 4u;
+    const uint32_t voff = ((live ? frame : 0u) * (uint32_t)N + (uint32_t)elem_index<M, LO, W>(tau, 0)) * 4u;
+    if constexpr (FX == 0 || FX == 1) {
+      // no stage option: the beats stay packed {re[31:16], im[15:0]} (RspChainTesterUtils.scala:105-109) from HBM to the magnitude
+      uint32_t z[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        z[e] = stream_load(reinterpret_cast<const uint32_t*>(gbase + (size_t)voff + (size_t)sample_offset<M>(e) * 4u));
+      if (rg.window) {  // Q1.15 coefficient, product rounded half-up back to 16 bits (spec section 2.1)
+        const int16_t* wt = reinterpret_cast<const int16_t*>(rg.window) + elem_index<M, LO, W>(tau, 0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int wq = wt[sample_offset<M>(e)];
+          const int re = ((int)(short)(z[e] >> 16) * wq + (1 << 14)) >> 15, im = ((int)(short)(z[e] & 0xffffu) * wq + (1 << 14)) >> 15;
+          z[e] = ((uint32_t)re << 16) | ((uint32_t)im & 0xffffu);
+        }
+      }
+      // twiddle ROM -> LDS once per workgroup (the sample loads above are already in flight)
+      fx_rom_fill(rom, twq, N / 2, threadIdx.x, wg_size(M));
+      __syncthreads();
+      fft_fx_frame_pk<M, FX == 0>(z, tau, fbase, rom, rg, hk);
+      if (hk.off(4)) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mg[e] = (int)(z[e] >> 16) & 32767;
+      } else if (rg.mag_mode == 2) {
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) jpl_fx_pair(z[e], z[e + 1], mg[e], mg[e + 1]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mg[e] = mag_fx((int)(short)(z[e] >> 16), (int)(short)(z[e] & 0xffffu), rg, log_lut);
+      }
+    } else {
+      int xr[16], xi[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        // beat = {re[31:16], im[15:0]}: RspChainTesterUtils.scala:105-109
-        const size_t eo = (size_t)sample_offset<M>(e) * 4u;
-        const uint32_t b = stream_load(reinterpret_cast<const uint32_t*>(gbase + (size_t)voff + eo));
+        const uint32_t b = stream_load(reinterpret_cast<const uint32_t*>(gbase + (size_t)voff + (size_t)sample_offset<M>(e) * 4u));
         xr[e] = (int)(short)(b >> 16);
         xi[e] = (int)(short)(b & 0xffffu);
       }
-      if (rg.window) {  // Q1.15 coefficient, product rounded half-up back to 16 bits (spec section 2.1)
+      if (rg.window) {
         const int16_t* wt = reinterpret_cast<const int16_t*>(rg.window) + elem_index<M, LO, W>(tau, 0);
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -177,20 +204,19 @@ __device__ __forceinline__ void front_end(const void* __restrict__ in, uint32_t 
           xi[e] = (int)(short)((xi[e] * wq + (1 << 14)) >> 15);
         }
       }
-    }
-    // twiddle ROM -> LDS once per workgroup (the sample loads above are already in flight)
-    fx_rom_fill(rom, twq, N / 2, threadIdx.x, wg_size(M));
-    __syncthreads();
-    fft_fx_frame<M, FX>(xr, xi, tau, fbase, rom, rg, hk);
-    if (hk.off(4)) {
+      fx_rom_fill(rom, twq, N / 2, threadIdx.x, wg_size(M));
+      __syncthreads();
+      fft_fx_frame<M, FX>(xr, xi, tau, fbase, rom, rg, hk);
+      if (hk.off(4)) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) mg[e] = xr[e] & 32767;
-    } else if (rg.mag_mode == 2) {
+        for (int e = 0; e < 16; ++e) mg[e] = xr[e] & 32767;
+      } else if (rg.mag_mode == 2) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) mg[e] = jpl_fx(xr[e], xi[e]);
-    } else {
+        for (int e = 0; e < 16; ++e) mg[e] = jpl_fx(xr[e], xi[e]);
+      } else {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) mg[e] = mag_fx(xr[e], xi[e], rg, log_lut);
+        for (int e = 0; e < 16; ++e) mg[e] = mag_fx(xr[e], xi[e], rg, log_lut);
+      }
     }
   }
 }

@@ -663,42 +663,51 @@ __device__ __forceinline__ void pass_fx_opt(int (&xr)[16], int (&xi)[16], int ta
 // FX selects the path at compile time -- 0: convergent trim (3-op closed form), 1: floor / half-up, 2: stage options;
 // -1: by the register snapshot at run time.  One kernel holding all three paths carries the registers of the widest
 // (the stage-option path: 180 VGPRs against 77-140 for the others), i.e. half the occupancy for every configuration.
+// The packed form: z[e] = {re[31:16], im[15:0]} (the beat format) in and out, trim path CONV (convergent) or the
+// floor / half-up pair -- what front_end and the 2-D kernels call when no stage option is set.
+template <int M, bool CONV, typename Hooks = NoHooks>
+__device__ __forceinline__ void fft_fx_frame_pk(uint32_t (&z)[16], int tau, unsigned char* fbase, const uint2* rom,
+                                                const ChainRegs& rg, Hooks hk = Hooks{}) {
+  constexpr int NP = plan_np(M);
+  uint32_t* buf = reinterpret_cast<uint32_t*>(fbase);
+  if (!hk.off(0)) pass_fx_pk<M, 0, CONV>(z, tau, rom, rg);
+  auto exchange = [&](auto pc) {
+    constexpr int P = decltype(pc)::value;
+    constexpr int W0 = plan_w(M, P - 1), LO0 = plan_lo(M, P - 1);
+    constexpr int W1 = plan_w(M, P), LO1 = plan_lo(M, P);
+    constexpr bool LAST = P == NP - 1;
+    if (!hk.off(3)) {
+#pragma unroll
+    for (int g = 0; g < (16 >> W0); ++g) {
+      uint32_t* b0 = buf + slot_base<M, LO0, W0, LAST>(tau, g);
+#pragma unroll
+      for (int r = 0; r < (1 << W0); ++r) b0[slot_delta<M, LO0, W0>(r)] = z[g * (1 << W0) + r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < (16 >> W1); ++g) {
+      const uint32_t* b1 = buf + slot_base<M, LO1, W1, LAST>(tau, g);
+#pragma unroll
+      for (int r = 0; r < (1 << W1); ++r) z[g * (1 << W1) + r] = b1[slot_delta<M, LO1, W1>(r)];
+    }
+    }
+    if (!hk.off(0)) pass_fx_pk<M, P, CONV>(z, tau, rom, rg);
+  };
+  exchange(std::integral_constant<int, 1>{});
+  if constexpr (NP > 2) exchange(std::integral_constant<int, 2>{});
+  if constexpr (NP > 3) exchange(std::integral_constant<int, 3>{});
+}
+
 template <int M, int FX = -1, typename Hooks = NoHooks>
 __device__ __forceinline__ void fft_fx_frame(int (&xr)[16], int (&xi)[16], int tau, unsigned char* fbase,
                                              const uint2* rom, const ChainRegs& rg, Hooks hk = Hooks{}) {
   constexpr int NP = plan_np(M);
-  uint32_t* buf = reinterpret_cast<uint32_t*>(fbase);
   auto run = [&](auto conv_c) {
     constexpr bool CONV = decltype(conv_c)::value;
     uint32_t z[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) z[e] = ((uint32_t)xr[e] << 16) | ((uint32_t)xi[e] & 0xffffu);  // folds away behind a beat's unpacking
-    if (!hk.off(0)) pass_fx_pk<M, 0, CONV>(z, tau, rom, rg);
-    auto exchange = [&](auto pc) {
-      constexpr int P = decltype(pc)::value;
-      constexpr int W0 = plan_w(M, P - 1), LO0 = plan_lo(M, P - 1);
-      constexpr int W1 = plan_w(M, P), LO1 = plan_lo(M, P);
-      constexpr bool LAST = P == NP - 1;
-      if (!hk.off(3)) {
-#pragma unroll
-      for (int g = 0; g < (16 >> W0); ++g) {
-        uint32_t* b0 = buf + slot_base<M, LO0, W0, LAST>(tau, g);
-#pragma unroll
-        for (int r = 0; r < (1 << W0); ++r) b0[slot_delta<M, LO0, W0>(r)] = z[g * (1 << W0) + r];
-      }
-      __syncthreads();
-#pragma unroll
-      for (int g = 0; g < (16 >> W1); ++g) {
-        const uint32_t* b1 = buf + slot_base<M, LO1, W1, LAST>(tau, g);
-#pragma unroll
-        for (int r = 0; r < (1 << W1); ++r) z[g * (1 << W1) + r] = b1[slot_delta<M, LO1, W1>(r)];
-      }
-      }
-      if (!hk.off(0)) pass_fx_pk<M, P, CONV>(z, tau, rom, rg);
-    };
-    exchange(std::integral_constant<int, 1>{});
-    if constexpr (NP > 2) exchange(std::integral_constant<int, 2>{});
-    if constexpr (NP > 3) exchange(std::integral_constant<int, 3>{});
+    fft_fx_frame_pk<M, CONV>(z, tau, fbase, rom, rg, hk);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       xr[e] = (int)(short)(z[e] >> 16);
@@ -761,6 +770,25 @@ __device__ __forceinline__ int jpl_fx(int re, int im) {
   const int u = max(ar, ai), v = min(ar, ai);
   const int m = max(u + (v >> 3), ((7 * u) >> 3) + (v >> 1));
   return min(m, 32767);
+}
+
+// jpl_fx of TWO packed bins at once (z = {re[31:16], im[15:0]}): the halves are regrouped into {re0, re1} / {im0, im1}
+// and everything runs on unsigned 16-bit lanes -- |-32768| = 0x8000 is a valid u16, the sums stay below 2^16, and
+// (7 u) >> 3 = u - ((u + 7) >> 3) avoids the 19-bit product.  19 operations per pair against 2 x (14 + 2 to unpack).
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void jpl_fx_pair(uint32_t z0, uint32_t z1, int& m0, int& m1) {
+  const s16x2 zero2 = {0, 0};
+  const s16x2 re = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(z1, z0, 0x07060302u));  // {z0.hi, z1.hi} = {re0 (lo), re1 (hi)}
+  const s16x2 im = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(z1, z0, 0x05040100u));  // {z0.lo, z1.lo}
+  const u16x2 ar = __builtin_bit_cast(u16x2, __builtin_elementwise_max(re, zero2 - re));
+  const u16x2 ai = __builtin_bit_cast(u16x2, __builtin_elementwise_max(im, zero2 - im));
+  const u16x2 u = __builtin_elementwise_max(ar, ai), v = __builtin_elementwise_min(ar, ai);
+  const u16x2 k1 = {1, 1}, k3 = {3, 3}, k7 = {7, 7}, kmax = {32767, 32767};
+  const u16x2 t1 = u + (v >> k3);
+  const u16x2 t2 = (u - ((u + k7) >> k3)) + (v >> k1);
+  const uint32_t m = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_elementwise_max(t1, t2), kmax));
+  m0 = (int)(m & 0xffffu);
+  m1 = (int)(m >> 16);
 }
 
 __device__ __forceinline__ int mag_fx(int re, int im, const ChainRegs& rg,
