@@ -279,25 +279,21 @@ range_fx_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uin
   unsigned char* fbase = smem + (size_t)fl * fft_image_slots(M) * 4;
   uint2* rom = reinterpret_cast<uint2*>(smem + (((size_t)FPW * fft_image_slots(M) * 4 + 7) & ~size_t(7)));
   const uint32_t* src = in + (size_t)(live ? row : 0) * N + first_sample<M>(tau);
-  int xr[16], xi[16];
+  uint32_t z[16];   // beats stay packed {re[31:16], im[15:0]} from HBM to HBM
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const uint32_t b = src[sample_offset<M>(e)];
-    xr[e] = (int)(short)(b >> 16);
-    xi[e] = (int)(short)(b & 0xffffu);
-  }
+  for (int e = 0; e < 16; ++e) z[e] = src[sample_offset<M>(e)];
   if (rg.window) {  // Q1.15 coefficient, product rounded half-up back to 16 bits (spec section 2.1)
     const int16_t* wt = reinterpret_cast<const int16_t*>(rg.window) + first_sample<M>(tau);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int wq = wt[sample_offset<M>(e)];
-      xr[e] = (int)(short)((xr[e] * wq + (1 << 14)) >> 15);
-      xi[e] = (int)(short)((xi[e] * wq + (1 << 14)) >> 15);
+      const int re = ((int)(short)(z[e] >> 16) * wq + (1 << 14)) >> 15, im = ((int)(short)(z[e] & 0xffffu) * wq + (1 << 14)) >> 15;
+      z[e] = ((uint32_t)re << 16) | ((uint32_t)im & 0xffffu);
     }
   }
   fx_rom_fill(rom, twq, N / 2, tid, wg_size(M));
   __syncthreads();
-  fft_fx_frame<M, FX>(xr, xi, tau, fbase, rom, rg);
+  fft_fx_frame_pk<M, FX == 0>(z, tau, fbase, rom, rg);
   constexpr int NP = plan_np(M), WL = plan_w(M, NP - 1);
   if (!live) return;
   const uint32_t ch = row / nd, d = row % nd;
@@ -308,7 +304,7 @@ range_fx_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uin
 #pragma unroll
     for (int p = 0; p < (1 << WL); ++p) {
       const int e = g * (1 << WL) + p;
-      dst[(size_t)((bitrev_c(p, WL) << (M - WL)) + g * T) * step] = ((uint32_t)xr[e] << 16) | ((uint32_t)xi[e] & 0xffffu);
+      dst[(size_t)((bitrev_c(p, WL) << (M - WL)) + g * T) * step] = z[e];
     }
   }
 }
@@ -331,26 +327,30 @@ doppler_fx_kernel(const uint32_t* __restrict__ in, int32_t* __restrict__ mag, ui
   const size_t col = (size_t)ch * ND * nr + map_index(0, r0 + fl, ND, nr, tile);
   const uint32_t pitch = tile ? kTileCols : nr;
   const uint32_t* src = in + col + (size_t)first_sample<MD>(tau) * pitch;
-  int xr[16], xi[16];
+  uint32_t z[16];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const uint32_t b = src[(size_t)sample_offset<MD>(e) * pitch];
-    xr[e] = (int)(short)(b >> 16);
-    xi[e] = (int)(short)(b & 0xffffu);
-  }
+  for (int e = 0; e < 16; ++e) z[e] = src[(size_t)sample_offset<MD>(e) * pitch];
   if (win) {
     const int16_t* wt = win + first_sample<MD>(tau);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int wq = wt[sample_offset<MD>(e)];
-      xr[e] = (int)(short)((xr[e] * wq + (1 << 14)) >> 15);
-      xi[e] = (int)(short)((xi[e] * wq + (1 << 14)) >> 15);
+      const int re = ((int)(short)(z[e] >> 16) * wq + (1 << 14)) >> 15, im = ((int)(short)(z[e] & 0xffffu) * wq + (1 << 14)) >> 15;
+      z[e] = ((uint32_t)re << 16) | ((uint32_t)im & 0xffffu);
     }
   }
   fx_rom_fill(rom, twq, ND / 2, tid, T * C);
   __syncthreads();
-  fft_fx_frame<MD, FX>(xr, xi, tau, fbase, rom, rg);
+  fft_fx_frame_pk<MD, FX == 0>(z, tau, fbase, rom, rg);
   constexpr int NP = plan_np(MD), WL = plan_w(MD, NP - 1);
+  int mg[16];
+  if (rg.mag_mode == 2) {
+#pragma unroll
+    for (int e = 0; e < 16; e += 2) jpl_fx_pair(z[e], z[e + 1], mg[e], mg[e + 1]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mg[e] = mag_fx((int)(short)(z[e] >> 16), (int)(short)(z[e] & 0xffffu), rg, log_lut);
+  }
   int32_t* dst = mag + (size_t)ch * ND * nr + map_index<kMagTileCols>(0, r0 + fl, ND, nr, tile);
   const uint32_t mpitch = tile ? kMagTileCols : nr;
 #pragma unroll
@@ -358,7 +358,7 @@ doppler_fx_kernel(const uint32_t* __restrict__ in, int32_t* __restrict__ mag, ui
 #pragma unroll
     for (int p = 0; p < (1 << WL); ++p) {
       const int e = g * (1 << WL) + p;
-      dst[(size_t)bin_of<MD>(tau, g, p) * mpitch] = mag_fx(xr[e], xi[e], rg, log_lut);
+      dst[(size_t)bin_of<MD>(tau, g, p) * mpitch] = mg[e];
     }
   }
 }
