@@ -153,7 +153,7 @@ template <int MD>
 __global__ void __launch_bounds__(threads_per_frame(MD) * kColsPerWg(MD))
 doppler_mag_kernel(const f32x2* __restrict__ in, float* __restrict__ mag, uint32_t n_ch, uint32_t nr, uint32_t tile,
                    int mag_mode, const f32x2* __restrict__ tw, const float* __restrict__ win) {
-  constexpr int ND = 1 << MD, T = threads_per_frame(MD), C = kColsPerWg(MD);
+  constexpr int ND = 1 << MD, C = kColsPerWg(MD);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // lanes run over the C adjacent range bins first: a wave touches 64 / C rows x (C x 8 B) segments
   const int tid = threadIdx.x, fl = tid % C, tau = tid / C;
@@ -364,8 +364,8 @@ doppler_fx_kernel(const uint32_t* __restrict__ in, int32_t* __restrict__ mag, ui
 }
 
 // ---------------------------------------------------------------- fused detection list
-// d_count = {found, stored} is the list's own cursor: the range pass (first launch of the batch) zeroes it, a wave /
-// cell that found peaks reserves its entries with ONE returning device-scope atomic on found and folds
+// d_count = {found, stored} is the list's own cursor: the range pass (first launch of the batch) zeroes it, a wave
+// that found peaks reserves its entries with ONE returning device-scope atomic on found and folds
 // min(found so far, cap) into stored with an atomic max (the maximum over all reservations is min(total, cap)).
 // No counters to clean, no finalize launch (4.8 us per batch as its own kernel).  Peaks are ~1e-5 of the cells.
 __device__ __forceinline__ uint32_t reserve_peaks(uint32_t* __restrict__ d_count, uint32_t cap, uint32_t n) {
@@ -373,19 +373,6 @@ __device__ __forceinline__ uint32_t reserve_peaks(uint32_t* __restrict__ d_count
   atomicMax(&d_count[1], base + n < cap ? base + n : cap);
   return base;
 }
-__device__ __forceinline__ void append_peak(rsp_detection* __restrict__ list, uint32_t cap, uint32_t* __restrict__ d_count,
-                                            uint32_t ch, uint32_t doppler, uint32_t range, uint32_t word) {
-  const uint32_t slot = reserve_peaks(d_count, cap, 1u);
-  if (slot < cap) {
-    rsp_detection d;
-    d.frame = ch;
-    d.bin = range;
-    d.doppler = doppler;
-    d.word = word;
-    list[slot] = d;
-  }
-}
-
 // ---------------------------------------------------------------- 2-D CA-CFAR
 // Training region = (2(ref_r+guard_r)+1) x (2(ref_d+guard_d)+1) box minus the guard box; out-of-map
 // range cells read zero (edge 0) or wrap (edge 1), Doppler is cyclic; statistic = sum / count.
@@ -514,6 +501,7 @@ cfar2d_kernel(const T* __restrict__ mag, uint32_t* __restrict__ out, uint32_t nd
       for (int k = -hd; k < -guard_d; ++k) up += mcol[k * MS];
     }
     const float kAh = 2.0f * kAc;  // a half holds count / 2 cells
+    uint32_t hits = 0u;  // bit j: output row dseg + j of this thread's column is a peak
 #pragma unroll
     for (int j = 0; j < kTD / 4; ++j) {
       const T cut = m[(dseg + j + hd) * MS + c + hr];
@@ -537,9 +525,33 @@ cfar2d_kernel(const T* __restrict__ mag, uint32_t* __restrict__ out, uint32_t nd
         wd = (__float_as_uint(thr) & ~1u) | (uint32_t)((float)cut > thr);
       }
       dst[(size_t)j * nr] = wd;
-      if (det_list && (wd & 1u)) append_peak(det_list, det_cap, det_count, ch_base + ch, (uint32_t)(d0 + dseg + j), (uint32_t)(r0 + c), wd);
+      hits |= (wd & 1u) << j;
       so += co[(j + hd + 1) * (kTR + 1)] - co[(j - hd) * (kTR + 1)];
       si += ci[(j + guard_d + 1) * (kTR + 1)] - ci[(j - guard_d) * (kTR + 1)];
+    }
+    // fused detection list: ONE reservation per wave (a lane scan gives every lane its offset), the words re-read by
+    // the lane that wrote them -- one device atomic per PEAK made a dense scene cost hundreds of microseconds
+    if (det_list) {
+      const int lane = tid & 63;
+      const uint32_t mine = (uint32_t)__popc(hits);
+      uint32_t incl = mine;
+#pragma unroll
+      for (int sh = 1; sh < 64; sh <<= 1) {
+        const uint32_t t = __shfl_up(incl, sh);
+        if (lane >= sh) incl += t;
+      }
+      const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      if (total) {
+        uint32_t base = 0u;
+        if (lane == 0) base = reserve_peaks(det_count, det_cap, total);
+        uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + incl - mine;
+        while (hits) {
+          const int j = __ffs(hits) - 1;
+          hits &= hits - 1;
+          if (pos < det_cap) det_list[pos] = rsp_detection{ch_base + ch, (uint32_t)(r0 + c), (uint32_t)(d0 + dseg + j), dst[(size_t)j * nr]};
+          ++pos;
+        }
+      }
     }
   }
 }
