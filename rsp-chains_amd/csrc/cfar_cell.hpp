@@ -29,7 +29,7 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
   SideHooks hk;
   hk.init(rg);
   front_end<M, FIXED, V, FX>(in, frame, live, tau, fbase, rg, tw, log_lut,
-                             reinterpret_cast<uint2*>(smem + (size_t)L::BYTES * FPW), mg, hk);
+                             reinterpret_cast<uint2*>(smem + (FIXED ? FixedRom<M, FX>::off(L::BYTES) : 0)), mg, hk);
 
   // ---- magnitudes to LDS in natural bin order ----
   V* mag = reinterpret_cast<V*>(fbase + L::MAG_OFF);

@@ -346,7 +346,7 @@ chain1d_gos_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint
   hk.init(rg);
 // (side builds, -DRSP_ABLATE: mask bit 5 reads 64 resident frames instead of the batch, bit 6 drops the word stores)
   front_end<M, FIXED, V, FX>(in, hk.off(5) ? (frame & 63u) : frame, live, tau, fbase, rg, tw, log_lut,
-                             reinterpret_cast<uint2*>(smem + (size_t)lay.frame_bytes * FPW), mg, hk);
+                             reinterpret_cast<uint2*>(smem + (FIXED ? FixedRom<M, FX>::off(lay.frame_bytes) : 0)), mg, hk);
 
   // LDS images of the tail, all unpadded (a thread's run of window starts puts its lanes RUN = 17 words apart: odd,
   // conflict-free; the cells are handled as quads of four, like the CA tail):

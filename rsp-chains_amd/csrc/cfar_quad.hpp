@@ -48,23 +48,6 @@ struct QuadLds {
   static constexpr int ROM_BYTES = fx_rom_bytes(M);
 };
 
-// FIXED16: the workgroup's LDS with the twiddle ROM.  The ROM is read by the FFT only, and the packed exchange image
-// of a frame fills the lower half of its region only (4-byte slots), so the ROM OVERLAYS the upper part of the last
-// frame's region -- the tail's first barrier ("done reading the FFT image") also ends every ROM read before a tail
-// image is written over it.  4096 points: 34.9 KiB instead of 34.9 + 17.5 per workgroup = four workgroups per CU
-// instead of three (1024 points: 38 KiB instead of 42.4, likewise; 8192: two instead of one).  The stage-option path
-// (FX = 2) exchanges 8-byte slots that fill the region: its ROM stays behind the frames.
-template <int M, bool SMALL, bool SHORTW, int FX>
-struct QuadFixedLds {
-  using L = QuadLds<M, SMALL, SHORTW>;
-  static constexpr int FPW = frames_per_wg(M);
-  static constexpr int IMG = (4 * fft_image_slots(M) + 7) & ~7;  // one frame's packed exchange image
-  static constexpr bool OVERLAY = FX != 2;
-  static constexpr int LOW = (FPW - 1) * L::BYTES + IMG, HIGH = FPW * L::BYTES - L::ROM_BYTES;
-  static constexpr int ROM_OFF = OVERLAY ? (LOW > HIGH ? LOW : HIGH) : FPW * L::BYTES;
-  static constexpr int TOTAL = ROM_OFF + L::ROM_BYTES > FPW * L::BYTES ? ROM_OFF + L::ROM_BYTES : FPW * L::BYTES;
-};
-
 // the geometry the quad tail is built for (host-side dispatch, launch_m)
 __host__ __device__ inline bool quad_tail_supports(int log2n, const ChainRegs& rg) {
   (void)log2n;
@@ -527,7 +510,7 @@ chain1d_quad_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uin
   hk.stamp(0);
 // (side builds, -DRSP_ABLATE: mask bit 5 reads 64 L2-resident frames instead of the batch, bit 6 drops the word stores)
   front_end<M, FIXED, V, FX>(in, hk.off(5) ? (frame & 63u) : frame, live, tau, fbase, rg, tw, log_lut,
-                             reinterpret_cast<uint2*>(smem + (FIXED ? QuadFixedLds<M, SMALL, SHORTW, FX>::ROM_OFF : 0)), mg, hk);
+                             reinterpret_cast<uint2*>(smem + (FIXED ? FixedRom<M, FX>::off(L::BYTES) : 0)), mg, hk);
   hk.stamp(7);
   quad_tail<M, FIXED, SMALL, SHORTW>(fbase, mg, tau, frame, live, rg, hk.off(6) ? nullptr : out, fcount, fdet, hk);
 }

@@ -28,7 +28,7 @@ static hipError_t launch_gos(const Chain1dLaunch& a) {
   const uint32_t fpw = frames_per_wg(M);
   const uint32_t grid = (a.n_frames + fpw - 1) / fpw;
   const GosLayout lay = gos_layout<M>(a.regs);
-  const size_t lds = (size_t)lay.frame_bytes * fpw + (kPartFixed ? FrameLds<M>::ROM_BYTES : 0);
+  const size_t lds = kPartFixed ? (size_t)FixedRom<M, kPartFx>::total(lay.frame_bytes) : (size_t)lay.frame_bytes * fpw;
   auto go = [&](auto k, LdsGrant& g) -> hipError_t {
     hipError_t err = grant_lds(k, lds, a.device, g);
     if (err != hipSuccess) return err;
@@ -62,7 +62,7 @@ static hipError_t launch_quad(const Chain1dLaunch& a) {
     auto go = [&](auto small_c, auto short_c, LdsGrant& granted) -> hipError_t {
       constexpr bool SMALL = decltype(small_c)::value, SHORTW = decltype(short_c)::value;
       using L = QuadLds<M, SMALL, SHORTW>;
-      const size_t lds = kPartFixed ? (size_t)QuadFixedLds<M, SMALL, SHORTW, FX>::TOTAL : (size_t)L::BYTES * fpw;
+      const size_t lds = kPartFixed ? (size_t)FixedRom<M, FX>::total(L::BYTES) : (size_t)L::BYTES * fpw;
       auto k = chain1d_quad_kernel<M, kPartFixed, FX, SMALL, SHORTW>;
       hipError_t e = grant_lds(k, lds, a.device, granted);
       if (e != hipSuccess) return e;
@@ -86,7 +86,7 @@ static hipError_t launch_m(const Chain1dLaunch& a) {
   if (quad_tail_supports(M, a.regs) && !a.force_generic_tail) return launch_quad<M>(a);
   const uint32_t fpw = frames_per_wg(M);
   const uint32_t grid = (a.n_frames + fpw - 1) / fpw;
-  const size_t lds = FrameLds<M>::BYTES * fpw + (kPartFixed ? FrameLds<M>::ROM_BYTES : 0);
+  const size_t lds = kPartFixed ? (size_t)FixedRom<M, kPartFx>::total(FrameLds<M>::BYTES) : (size_t)FrameLds<M>::BYTES * fpw;
   return with_fx(a, [&](auto fx) -> hipError_t {
     constexpr int FX = decltype(fx)::value;
     static LdsGrant granted;

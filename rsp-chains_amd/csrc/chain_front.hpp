@@ -49,6 +49,28 @@ struct FrameLds {
   static constexpr int ROM_BYTES = fx_rom_bytes(M);  // FIXED16: LDS copy of the Q2.14 twiddle ROM ({W1, W2} per twiddle: fx_rom_entry), per workgroup
 };
 
+// FIXED16: where the twiddle ROM of a chain workgroup lives.  The ROM is read by the FFT only, and the packed exchange
+// image of a frame fills the lower half of its region only (4-byte slots), so the ROM OVERLAYS the upper part of the last
+// frame's region: every chain kernel's tail starts with a barrier ("done reading the FFT image") that also ends all ROM
+// reads before a tail image is written over it.  4096 points, quad kernel: 34.9 KiB per workgroup instead of 34.9 + 17.5 =
+// four workgroups per CU instead of three; 8192 points: two instead of one (the GOS kernel at the cfg-4 shape on FIXED16:
+// 147 -> 104 us).  The stage-option path (FX = 2) exchanges 8-byte slots that fill the region: its ROM stays behind the frames.
+// frame_bytes = the kernel's LDS per frame (a multiple of 16).
+template <int M, int FX>
+struct FixedRom {
+  static constexpr int FPW = frames_per_wg(M);
+  static constexpr int IMG = (4 * fft_image_slots(M) + 7) & ~7;  // one frame's packed exchange image
+  static constexpr int ROM = fx_rom_bytes(M);
+  static constexpr bool OVERLAY = FX != 2;
+  static __host__ __device__ constexpr int off(int frame_bytes) {
+    const int low = (FPW - 1) * frame_bytes + IMG, high = FPW * frame_bytes - ROM;
+    return OVERLAY ? (low > high ? low : high) : FPW * frame_bytes;
+  }
+  static __host__ __device__ constexpr int total(int frame_bytes) {
+    return off(frame_bytes) + ROM > FPW * frame_bytes ? off(frame_bytes) + ROM : FPW * frame_bytes;
+  }
+};
+
 __device__ __forceinline__ int mag_slot(int x) { return pad(x + 16); }
 __device__ __forceinline__ int pb_slot(int x) { return pad(x + kHalo); }
 

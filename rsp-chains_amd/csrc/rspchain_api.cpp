@@ -493,8 +493,7 @@ int launch_frames(rsp_chain* c, const void* d_in, size_t n_frames, uint32_t* d_o
   const hipError_t le = rsp::launch_chain1d(a);
   if (le == hipErrorOutOfMemory)
     return fail(RSP_ERR_UNSUPPORTED, "%d-point frames: this CFAR configuration needs more than the 160 KiB of LDS of a workgroup "
-                "(16384 points hold CA / GO / SO with window sizes that are multiples of 4, and the fp32 ordered statistic with "
-                "indexLagg = indexLead)", 1 << a.log2n);
+                "(16384 points do not hold the ordered statistic with indexLagg != indexLead, nor the FFT stage options)", 1 << a.log2n);
   HIP_TRY(le);
   return RSP_OK;
 }

@@ -458,13 +458,24 @@ def test_16384_point_frames(gpu):
     beats = random_beats(3, n, 79)
     got = run_fixed(wide, rt, beats)
     assert np.array_equal(got, O.chain_fixed(beats, oracle_cfg(wide, rt)).reshape(got.shape))
-    # per-cell tail (window sizes that are not multiples of 4) + FIXED16 twiddle ROM: 215 KiB
+    # per-cell tail (window sizes that are not multiples of 4) and the ordered statistic on FIXED16: the twiddle ROM
+    # overlays the frame's LDS region, so both fit (145 / 140 KiB)
     odd = R.RunTimeRspChainParams(fftSize=n, refWindowSize=8, guardWindowSize=3, divSum=3)
-    with R.FftMagCfarChainVanilla(params) as dut:
-        dut.configure(odd)
+    got = run_fixed(params, odd, beats)
+    assert np.array_equal(got, O.chain_fixed(beats, oracle_cfg(params, odd)).reshape(got.shape))
+    gos = make_params(n, alg=R.GOSCFARType, guard=8)
+    rtg = R.RunTimeRspChainParams(fftSize=n, CFARMode="Greatest Of", refWindowSize=32, guardWindowSize=4, divSum=None,
+                                  indexLagg=24, indexLead=24, thresholdScaler=1.5)
+    got = run_fixed(gos, rtg, beats)
+    assert np.array_equal(got, O.chain_fixed(beats, oracle_cfg(gos, rtg)).reshape(got.shape))
+    # what does not fit: two order-statistic arrays (indexLagg != indexLead) beside the magnitudes, 207 KiB
+    rt2 = R.RunTimeRspChainParams(fftSize=n, CFARMode="Greatest Of", refWindowSize=32, guardWindowSize=4, divSum=None,
+                                  indexLagg=24, indexLead=8, thresholdScaler=1.5)
+    with R.FftMagCfarChainVanilla(gos) as dut:
+        dut.configure(rt2)
         with pytest.raises(NotImplementedError, match="160 KiB"):
             dut.stream(beats)
-        dut.configure(rt)                               # the object is still usable
+        dut.configure(rtg)                              # the object is still usable
         assert dut.stream(beats).shape == (3, n)
     # the 2-D chain keeps its 8192-point range FFT
     with pytest.raises(NotImplementedError, match="range FFT holds up to 8192"):
