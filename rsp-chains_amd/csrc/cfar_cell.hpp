@@ -154,12 +154,18 @@ chain1d_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t
             const int a = side == 0 ? k - G - R : k + G + 1;
             V b = V(0);
             bool first = true;
+            // consecutive sub-windows share a boundary: its prefix and block index are carried, not looked up again
+            V pu = pb[pb_slot(a)];
+            int bu = a >> sh;
             for (int s0 = 0; s0 + rg.sub_window <= R; s0 += rg.sub_window) {
-              const int u = a + s0, v = u + rg.sub_window;
-              V ss = pb[pb_slot(v)] - pb[pb_slot(u)];
-              if ((v >> sh) != (u >> sh)) ss += bs[u >> sh];
+              const int v = a + s0 + rg.sub_window, bv = v >> sh;
+              const V pv = pb[pb_slot(v)];
+              V ss = pv - pu;
+              if (bv != bu) ss += bs[bu];
               b = first ? ss : (ss > b ? ss : b);
               first = false;
+              pu = pv;
+              bu = bv;
             }
             best[side] = b;
           }
