@@ -405,8 +405,22 @@ chain1d_gos_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint
           if (rg.idx_lagg == rg.idx_lead && rg.idx_lagg == 24) gos_stage_split2<V, 24>(mag, o1, tau, rg.G);
           else if (rg.idx_lagg == rg.idx_lead && rg.idx_lagg == 16) gos_stage_split2<V, 16>(mag, o1, tau, rg.G);
           else gos_stage_split<V, 32, 17>(mag, o1, o2, tau, rg.G, rg.idx_lagg, rg.idx_lead);
+          break;
         }
-        else gos_stage<V, 32>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead);
+        // 256- / 512-point frames: 16 / 32 threads per frame walk 18 - 20 window starts each; the same split with a
+        // longer sliding part (a sorted 32-cell window slid 18 times costs 94 operations per start)
+        if constexpr (M <= 9) {
+          auto split_run = [&](auto run_c) {
+            constexpr int RUN = decltype(run_c)::value;
+            if (rg.idx_lagg == rg.idx_lead && rg.idx_lagg == 24) gos_stage_split<V, 32, RUN, 24>(mag, o1, o2, tau, rg.G, 24, 24);
+            else if (rg.idx_lagg == rg.idx_lead && rg.idx_lagg == 16) gos_stage_split<V, 32, RUN, 16>(mag, o1, o2, tau, rg.G, 16, 16);
+            else gos_stage_split<V, 32, RUN>(mag, o1, o2, tau, rg.G, rg.idx_lagg, rg.idx_lead);
+          };
+          constexpr int RUN0 = M == 9 ? 18 : 19;   // 2 G + 33 window starts beyond the frame's cells, G < 16 / G < 8
+          if (RSP_GOS_SPLIT && lay.run == RUN0) { split_run(std::integral_constant<int, RUN0>{}); break; }
+          if (RSP_GOS_SPLIT && lay.run == RUN0 + 1) { split_run(std::integral_constant<int, RUN0 + 1>{}); break; }
+        }
+        gos_stage<V, 32>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead);
         break;
     }
   }

@@ -281,7 +281,9 @@ def test_cpp_host_tester_replays_dumps(gpu, tmp_path):
 @pytest.mark.parametrize("n,ref,guard,idx", [(256, 4, 1, (1, 2)), (1024, 16, 2, (11, 11)), (1024, 32, 4, (24, 8)),
                                             (4096, 64, 4, (48, 48)), (8192, 32, 4, (24, 24)), (8192, 64, 4, (40, 13)),
                                             # the two-run stage with a compile-time index (k = R/2, 3R/4 of 32), odd guards
-                                            (4096, 32, 3, (16, 16)), (2048, 32, 1, (24, 24)), (512, 32, 3, (16, 16))])
+                                            (4096, 32, 3, (16, 16)), (2048, 32, 1, (24, 24)), (512, 32, 3, (16, 16)),
+                                            # 256- / 512-point frames: 18 - 20 window starts per thread on the split path
+                                            (512, 32, 4, (20, 9)), (256, 32, 2, (24, 24)), (256, 32, 4, (7, 30))])
 @pytest.mark.parametrize("mode", ["Cell Averaging", "Greatest Of", "Smallest Of"])
 def test_fixed_gos_bit_exact(gpu, n, ref, guard, idx, mode):
     """GOSCFARType (FftMagCfarChainTester.scala:105,123-127): ordered-statistic CFAR, bit-exact."""
@@ -482,3 +484,22 @@ def test_16384_point_frames(gpu):
         R.FftMagCfarChainVanilla(R.FftMagCfarVanillaParameters(
             fftParams=R.FFTParams.fixed(numPoints=n), magParams=R.MAGParams.fixed(),
             cfarParams=R.CFARParams(fftSize=n, leadLaggWindowSize=16), dtype=R.F32, dopplerPoints=256, refDoppler=8, guardDoppler=2))
+
+
+@pytest.mark.parametrize("n,guard,idx", [(512, 20, (24, 24)), (512, 9, (16, 16)), (256, 12, (24, 24)), (256, 5, (3, 17))])
+def test_gos_short_frames_wide_guards(gpu, n, guard, idx):
+    """Ordered statistic on 256- / 512-point frames with guard windows that change the number of window starts per thread
+    (18 / 19 at 512 points, 19 / 20 at 256): every split-path instantiation, FIXED16 bit-exact and fp32 in tolerance."""
+    rt = R.RunTimeRspChainParams(fftSize=n, CFARMode="Smallest Of", refWindowSize=32, guardWindowSize=guard, divSum=None,
+                                 indexLagg=idx[0], indexLead=idx[1], thresholdScaler=1.5)
+    params = make_params(n, alg=R.GOSCFARType, guard=32)
+    beats = np.concatenate([tone_beats(2, n, 90 + n), random_beats(9, n, n + 3)])
+    got = run_fixed(params, rt, beats)
+    assert np.array_equal(got, O.chain_fixed(beats, oracle_cfg(params, rt)).reshape(got.shape))
+    pf = make_params(n, dtype=R.F32, alg=R.GOSCFARType, guard=32)
+    x = R.stimulus.chirp_frames(5, n, seed=77 + guard)
+    with R.FftMagCfarChainVanilla(pf) as dut:
+        dut.configure(rt)
+        words = dut.stream(x)
+    thr, peak, margin, mag = O.chain_f32(x, oracle_fcfg(pf, rt), want_mag=True)
+    compare_f32(words, thr, peak, margin, mag)
