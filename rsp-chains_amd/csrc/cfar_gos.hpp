@@ -320,12 +320,17 @@ __device__ __forceinline__ void gos_stage_split2(const V* mag, V* o1, int tau, i
   }
 }
 
+// window starts per thread of the 64-cell window on the split path: ceil((N + 2 G + 65) / (N / 16)) for the guard
+// sizes up to 31 / 31 / 15 / 7 cells at 1024 / 2048+ / 512 / 256 points (other guards: the one-window path, KIND 2)
+__host__ __device__ constexpr int gos_big_run(int M) { return M >= 11 ? 17 : M == 10 ? 18 : M == 9 ? 19 : 21; }
+
 // BIG = the 64-cell window: its sorted window alone is 64 + 63 registers, so it is a kernel of its own -- as one path
 // of a common kernel it set the register count (141 + scratch) and with it the occupancy (one 512-thread workgroup
 // per CU at 8192 points) of every other window size.
-// KIND: 0 = windows up to 32 cells; 1 = the 64-cell window on the split path (17 starts per thread: every frame size
-// >= 1024); 2 = the 64-cell window, one sorted 64-cell vector slid over any number of starts (256 / 512-point frames:
-// its run-time pick of a 64-register vector goes through scratch memory, 640 B -- kept out of the other two).
+// KIND: 0 = windows up to 32 cells; 1 = the 64-cell window on the split path (gos_big_run(M) starts per thread: the run
+// of the usual guard sizes at each frame size); 2 = the 64-cell window, one sorted 64-cell vector slid over any number
+// of starts (guards that change the run at up to 2048 points: its run-time pick of a 64-register vector goes through
+// scratch memory, 640 B -- kept out of the other two).
 template <int M, bool FIXED, int KIND, int FX>
 __global__ void __launch_bounds__(wg_size(M))
 chain1d_gos_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint32_t n_frames,
@@ -392,7 +397,7 @@ chain1d_gos_kernel(const void* __restrict__ in, uint32_t* __restrict__ out, uint
   __syncthreads();
   if (hk.off(1)) {  // (side builds) no order-statistic stage: what the rest of the kernel costs
   } else if constexpr (KIND == 1) {
-    gos_stage_split<V, 64, 17>(mag, o1, o2, tau, rg.G, rg.idx_lagg, rg.idx_lead);
+    gos_stage_split<V, 64, gos_big_run(M)>(mag, o1, o2, tau, rg.G, rg.idx_lagg, rg.idx_lead);
   } else if constexpr (KIND == 2) {
     gos_stage<V, 64>(mag, o1, o2, tau, lay.run, rg.G, rg.idx_lagg, rg.idx_lead);
   } else {

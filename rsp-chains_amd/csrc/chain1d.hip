@@ -40,15 +40,11 @@ static hipError_t launch_gos(const Chain1dLaunch& a) {
     constexpr int FX = decltype(fx)::value;
     static LdsGrant g3[3];
     if (a.regs.R <= 32) return go(chain1d_gos_kernel<M, kPartFixed, 0, FX>, g3[0]);
-    // 64-cell window: run = 16 + ceil(16 (2 G + 65) / N) starts per thread -- always 17 from 4096 points up (G <= 63),
-    // never 17 up to 512 points, so each frame size instantiates only the kinds it can reach
-    const bool split = lay.run == 17 && RSP_GOS_SPLIT;
-    if constexpr (M >= 10) {
-      if (split) return go(chain1d_gos_kernel<M, kPartFixed, 1, FX>, g3[1]);
-    }
-    if constexpr (M <= 11) {
-      if (!split) return go(chain1d_gos_kernel<M, kPartFixed, 2, FX>, g3[2]);
-    }
+    // 64-cell window: run = ceil((N + 2 G + 65) / T) starts per thread; the split path is instantiated for the run of
+    // the usual guard sizes at each frame size (gos_big_run), the one-window path (scratch-memory picks) serves the rest
+    const bool split = lay.run == gos_big_run(M) && RSP_GOS_SPLIT;
+    if (split) return go(chain1d_gos_kernel<M, kPartFixed, 1, FX>, g3[1]);
+    if constexpr (M <= 11) return go(chain1d_gos_kernel<M, kPartFixed, 2, FX>, g3[2]);
     return hipErrorInvalidValue;
   });
 }

@@ -283,7 +283,9 @@ def test_cpp_host_tester_replays_dumps(gpu, tmp_path):
                                             # the two-run stage with a compile-time index (k = R/2, 3R/4 of 32), odd guards
                                             (4096, 32, 3, (16, 16)), (2048, 32, 1, (24, 24)), (512, 32, 3, (16, 16)),
                                             # 256- / 512-point frames: 18 - 20 window starts per thread on the split path
-                                            (512, 32, 4, (20, 9)), (256, 32, 2, (24, 24)), (256, 32, 4, (7, 30))])
+                                            (512, 32, 4, (20, 9)), (256, 32, 2, (24, 24)), (256, 32, 4, (7, 30)),
+                                            # the 64-cell window on the split path at 18 / 19 / 21 starts per thread
+                                            (1024, 64, 4, (48, 48)), (512, 64, 2, (10, 50)), (256, 64, 3, (32, 32))])
 @pytest.mark.parametrize("mode", ["Cell Averaging", "Greatest Of", "Smallest Of"])
 def test_fixed_gos_bit_exact(gpu, n, ref, guard, idx, mode):
     """GOSCFARType (FftMagCfarChainTester.scala:105,123-127): ordered-statistic CFAR, bit-exact."""
@@ -486,17 +488,19 @@ def test_16384_point_frames(gpu):
             cfarParams=R.CFARParams(fftSize=n, leadLaggWindowSize=16), dtype=R.F32, dopplerPoints=256, refDoppler=8, guardDoppler=2))
 
 
-@pytest.mark.parametrize("n,guard,idx", [(512, 20, (24, 24)), (512, 9, (16, 16)), (256, 12, (24, 24)), (256, 5, (3, 17))])
-def test_gos_short_frames_wide_guards(gpu, n, guard, idx):
+@pytest.mark.parametrize("n,ref,guard,idx", [(512, 32, 20, (24, 24)), (512, 32, 9, (16, 16)), (256, 32, 12, (24, 24)), (256, 32, 5, (3, 17)),
+                                             (1024, 64, 33, (48, 48)), (1024, 64, 31, (20, 60)), (512, 64, 17, (32, 32)), (256, 64, 9, (48, 5))])
+def test_gos_short_frames_wide_guards(gpu, n, ref, guard, idx):
     """Ordered statistic on 256- / 512-point frames with guard windows that change the number of window starts per thread
-    (18 / 19 at 512 points, 19 / 20 at 256): every split-path instantiation, FIXED16 bit-exact and fp32 in tolerance."""
-    rt = R.RunTimeRspChainParams(fftSize=n, CFARMode="Smallest Of", refWindowSize=32, guardWindowSize=guard, divSum=None,
+    (18 / 19 at 512 points, 19 / 20 at 256; the 64-cell window off its split path's run): every instantiation, FIXED16
+    bit-exact and fp32 in tolerance."""
+    rt = R.RunTimeRspChainParams(fftSize=n, CFARMode="Smallest Of", refWindowSize=ref, guardWindowSize=guard, divSum=None,
                                  indexLagg=idx[0], indexLead=idx[1], thresholdScaler=1.5)
-    params = make_params(n, alg=R.GOSCFARType, guard=32)
+    params = make_params(n, alg=R.GOSCFARType, guard=48)
     beats = np.concatenate([tone_beats(2, n, 90 + n), random_beats(9, n, n + 3)])
     got = run_fixed(params, rt, beats)
     assert np.array_equal(got, O.chain_fixed(beats, oracle_cfg(params, rt)).reshape(got.shape))
-    pf = make_params(n, dtype=R.F32, alg=R.GOSCFARType, guard=32)
+    pf = make_params(n, dtype=R.F32, alg=R.GOSCFARType, guard=48)
     x = R.stimulus.chirp_frames(5, n, seed=77 + guard)
     with R.FftMagCfarChainVanilla(pf) as dut:
         dut.configure(rt)
