@@ -373,6 +373,24 @@ __device__ __forceinline__ uint32_t reserve_peaks(uint32_t* __restrict__ d_count
   atomicMax(&d_count[1], base + n < cap ? base + n : cap);
   return base;
 }
+// The entries of a whole WORKGROUP (four waves) in one reservation: a dense scene gives every wave something to append, and
+// the reservations of all the launch's waves queue up on one address (~10 ns each: 0.7 ms per 16.7 M cells when every
+// 512-cell wave has a peak).  Every thread of the workgroup calls it with its wave's count n (wave-uniform); returns the
+// base of this wave's entries.  Two barriers at the very end of the kernels that use it.
+__device__ __forceinline__ uint32_t reserve_peaks_wg(uint32_t* __restrict__ d_count, uint32_t cap, uint32_t n, int wave, int lane) {
+  __shared__ uint32_t wave_n[4], wg_base;
+  if (lane == 0) wave_n[wave] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t tot = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3];
+    wg_base = tot ? reserve_peaks(d_count, cap, tot) : 0u;
+  }
+  __syncthreads();
+  uint32_t base = wg_base;
+  for (int i = 0; i < wave; ++i) base += wave_n[i];
+  return base;
+}
+
 // ---------------------------------------------------------------- 2-D CA-CFAR
 // Training region = (2(ref_r+guard_r)+1) x (2(ref_d+guard_d)+1) box minus the guard box; out-of-map
 // range cells read zero (edge 0) or wrap (edge 1), Doppler is cyclic; statistic = sum / count.
@@ -529,8 +547,9 @@ cfar2d_kernel(const T* __restrict__ mag, uint32_t* __restrict__ out, uint32_t nd
       so += co[(j + hd + 1) * (kTR + 1)] - co[(j - hd) * (kTR + 1)];
       si += ci[(j + guard_d + 1) * (kTR + 1)] - ci[(j - guard_d) * (kTR + 1)];
     }
-    // fused detection list: ONE reservation per wave (a lane scan gives every lane its offset), the words re-read by
-    // the lane that wrote them -- one device atomic per PEAK made a dense scene cost hundreds of microseconds
+    // fused detection list: ONE reservation per workgroup (a lane scan gives every lane its offset inside its wave's
+    // share), the words re-read by the lane that wrote them -- one device atomic per PEAK made a dense scene cost
+    // hundreds of microseconds
     if (det_list) {
       const int lane = tid & 63;
       const uint32_t mine = (uint32_t)__popc(hits);
@@ -541,10 +560,9 @@ cfar2d_kernel(const T* __restrict__ mag, uint32_t* __restrict__ out, uint32_t nd
         if (lane >= sh) incl += t;
       }
       const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      const uint32_t base = reserve_peaks_wg(det_count, det_cap, total, tid >> 6, lane);
       if (total) {
-        uint32_t base = 0u;
-        if (lane == 0) base = reserve_peaks(det_count, det_cap, total);
-        uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + incl - mine;
+        uint32_t pos = base + incl - mine;
         while (hits) {
           const int j = __ffs(hits) - 1;
           hits &= hits - 1;
@@ -810,11 +828,9 @@ cfar2d_walk_kernel(const S* __restrict__ mag, uint32_t* __restrict__ out, uint32
     }
   }
   if (det_list) {
-    const uint32_t n = stage_cnt[w];  // wave-private: this wave's LDS operations execute in order
+    const uint32_t n = stage_cnt[w];  // wave-private: this wave's LDS operations execute in order; exact even past kWalkStage
+    const uint32_t base = reserve_peaks_wg(det_count, det_cap, n, w, lane);  // once per workgroup that found something
     if (n > 0u && n <= (uint32_t)kWalkStage) {
-      uint32_t base = 0u;
-      if (lane == 0) base = reserve_peaks(det_count, det_cap, n);  // once per wave that found something
-      base = __builtin_amdgcn_readfirstlane(base);
       for (uint32_t k = lane; k < n; k += 64) {
         if (base + k < det_cap) {
           const u32x4 e = stage[w][k];
@@ -827,9 +843,9 @@ cfar2d_walk_kernel(const S* __restrict__ mag, uint32_t* __restrict__ out, uint32
         }
       }
     } else if (n > (uint32_t)kWalkStage) {
-      // more peaks than the staging holds (thresholds near the noise floor): every lane reads its own words back,
-      // the wave takes its n entries with ONE reservation (n is exact: the staging counter kept counting) and a lane
-      // writes its peaks behind those of the lanes before it.  (One atomic per PEAK here cost 460 us per 117 k peaks.)
+      // more peaks than the staging holds (thresholds near the noise floor): every lane reads its own words back and
+      // writes its peaks behind those of the lanes before it (a lane scan of the per-lane counts).  (One atomic per PEAK
+      // here cost 460 us per 117 k peaks.)
       uint32_t mine = 0u;
       if (owner) {
 #pragma unroll 1
@@ -844,9 +860,7 @@ cfar2d_walk_kernel(const S* __restrict__ mag, uint32_t* __restrict__ out, uint32
         const uint32_t t = __shfl_up(incl, sh);
         if (lane >= sh) incl += t;
       }
-      uint32_t base = 0u;
-      if (lane == 0) base = reserve_peaks(det_count, det_cap, n);
-      uint32_t pos = __builtin_amdgcn_readfirstlane(base) + incl - mine;
+      uint32_t pos = base + incl - mine;
       if (owner && mine) {
 #pragma unroll 1
         for (int i = 0; i < SEG; ++i) {
