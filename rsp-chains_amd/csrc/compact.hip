@@ -88,6 +88,57 @@ __device__ __forceinline__ uint32_t reserve_block(uint32_t* counters, uint32_t f
 // list is reserved with one returning atomic per workgroup (blocks land in completion order).
 constexpr uint32_t kPrefixFrames = 16384;
 
+// Frames whose peaks did not fit their slots (> kFrameDetCap: thresholds near the noise floor, clutter) are re-read from
+// the dense words.  Left to the slot stage's 16 workgroups -- one frame after the other, 256 frames each -- a scene in which
+// every frame overflows took 2.2 ms per 4096 x 4096 batch (48x the chain kernel).  The launch therefore carries helper
+// workgroups, 4 frames each: a helper reads its frames' counts, leaves at once when none overflows (the usual case: one
+// memory round trip next to the slot stage's own), and otherwise takes each overflowing frame's base from the same
+// prefix over the counts the slot stage uses -- no queue, no inter-workgroup signal, the list's order unchanged.
+constexpr uint32_t kOvfFramesPerWg = 4;
+__device__ __forceinline__ void overflow_helper(const uint32_t* __restrict__ fcount, uint32_t n_frames,
+                                                const uint32_t* __restrict__ words, int log2n, int word_shift,
+                                                rsp_detection* __restrict__ list, uint32_t cap, uint32_t h) {
+  __shared__ uint32_t cnt_sh[kOvfFramesPerWg], part[4], cursor;
+  const uint32_t f0 = h * kOvfFramesPerWg;
+  if (f0 >= n_frames || !words) return;
+  if (threadIdx.x < kOvfFramesPerWg) cnt_sh[threadIdx.x] = f0 + threadIdx.x < n_frames ? fcount[f0 + threadIdx.x] : 0u;
+  __syncthreads();
+  bool any = false;
+#pragma unroll
+  for (uint32_t j = 0; j < kOvfFramesPerWg; ++j) any |= cnt_sh[j] > (uint32_t)kFrameDetCap;
+  if (!any) return;  // uniform
+  // peaks of all the frames before f0 (a multiple of 4): with dense words every frame contributes its full count
+  uint32_t pre = 0u;
+  const u32x4* fc4 = reinterpret_cast<const u32x4*>(fcount);
+  for (uint32_t i = threadIdx.x; i < f0 / 4; i += 256) {
+    const u32x4 c = fc4[i];
+    pre += (c.x + c.y) + (c.z + c.w);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) pre += __shfl_xor(pre, d);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = pre;
+  __syncthreads();
+  uint32_t base = part[0] + part[1] + part[2] + part[3];
+  for (uint32_t j = 0; j < kOvfFramesPerWg; ++j) {
+    const uint32_t c = cnt_sh[j];
+    if (c > (uint32_t)kFrameDetCap) {  // uniform
+      if (threadIdx.x == 0) cursor = 0u;
+      __syncthreads();
+      const uint32_t of = f0 + j;
+      const uint32_t* row = words + (((size_t)of << log2n) << word_shift);  // word_shift = 1: 64-bit beats {word, cut}
+      for (uint32_t x = threadIdx.x; x < (1u << log2n); x += 256) {
+        const uint32_t w = row[(size_t)x << word_shift];
+        if (w & 1u) {
+          const uint32_t slot = base + atomicAdd(&cursor, 1u);
+          if (slot < cap) list[slot] = rsp_detection{of, x, 0u, w};
+        }
+      }
+      __syncthreads();
+    }
+    base += c;
+  }
+}
+
 template <bool PREFIX>
 __global__ void __launch_bounds__(256)
 compact_frames_kernel(const uint32_t* __restrict__ fcount, const uint2* __restrict__ fdet,
@@ -97,6 +148,13 @@ compact_frames_kernel(const uint32_t* __restrict__ fcount, const uint2* __restri
   __shared__ uint32_t wave_tot[4], wave_found[4], wave_pre[4], wave_pref[4];
   __shared__ uint32_t base_sh, ovf_n, ovf_cursor;
   __shared__ uint32_t ovf_frame[256], ovf_base[256];
+  const uint32_t n_main = (n_frames + 255) / 256;  // workgroups of the slot stage; any further ones are overflow helpers
+  if constexpr (PREFIX) {
+    if (blockIdx.x >= n_main) {
+      overflow_helper(fcount, n_frames, words, log2n, word_shift, list, cap, blockIdx.x - n_main);
+      return;
+    }
+  }
   const uint32_t f = blockIdx.x * 256 + threadIdx.x;
   const uint32_t found = f < n_frames ? fcount[f] : 0u;
   u32x4 early[8];  // slots 0..15 of the frame, requested before the count is known (stale slots are never used)
@@ -150,7 +208,7 @@ compact_frames_kernel(const uint32_t* __restrict__ fcount, const uint2* __restri
   if constexpr (PREFIX) {
     const uint32_t wg_base = wave_pre[0] + wave_pre[1] + wave_pre[2] + wave_pre[3];
     base = wg_base + off;
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    if (blockIdx.x == n_main - 1 && threadIdx.x == 0) {
       const uint32_t cursor = wg_base + tot;
       d_count[0] = wave_pref[0] + wave_pref[1] + wave_pref[2] + wave_pref[3] + fnd;
       d_count[1] = cursor < cap ? cursor : cap;
@@ -161,9 +219,11 @@ compact_frames_kernel(const uint32_t* __restrict__ fcount, const uint2* __restri
     base = base_sh + off;
   }
   if (ovf && words) {
-    const uint32_t s = atomicAdd(&ovf_n, 1u);
-    ovf_frame[s] = f;
-    ovf_base[s] = base;
+    if constexpr (!PREFIX) {  // (PREFIX: the overflow helpers of this launch re-read such frames, 4 frames per workgroup)
+      const uint32_t s = atomicAdd(&ovf_n, 1u);
+      ovf_frame[s] = f;
+      ovf_base[s] = base;
+    }
   } else {
     // the first 16 slots were requested together with the count (one memory round trip for all but ~1e-4 of the
     // frames at 5 peaks per frame); later slots four per round (two 16-byte loads)
@@ -219,7 +279,8 @@ hipError_t launch_compact_frames(const uint32_t* fcount, const uint2* fdet, uint
                                  uint32_t cap, uint32_t* counters, uint32_t* d_count, hipStream_t stream) {
   if (n_frames == 0) return hipMemsetAsync(d_count, 0, 2 * sizeof(uint32_t), stream);
   if (n_frames <= kPrefixFrames)
-    hipLaunchKernelGGL(compact_frames_kernel<true>, dim3((n_frames + 255) / 256), dim3(256), 0, stream,
+    hipLaunchKernelGGL(compact_frames_kernel<true>,
+                       dim3((n_frames + 255) / 256 + (words ? (n_frames + kOvfFramesPerWg - 1) / kOvfFramesPerWg : 0u)), dim3(256), 0, stream,
                        fcount, fdet, n_frames, words, log2n, word_shift, list, cap, counters, d_count);
   else
     hipLaunchKernelGGL(compact_frames_kernel<false>, dim3((n_frames + 255) / 256), dim3(256), 0, stream,
