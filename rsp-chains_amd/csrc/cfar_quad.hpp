@@ -120,17 +120,13 @@ __device__ __forceinline__ void quad_emit(const QuadWords word, const QuadCuts<V
   } else if (live && out) {
     char* obase = reinterpret_cast<char*>(out);
     const uint32_t ooff = (frame * (uint32_t)N + 4u * (uint32_t)tau) * 4u;
-#ifndef RSP_NO_PRIO
-    __builtin_amdgcn_s_setprio(3);
-#endif
+    wave_prio(1);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const u32x4 w4 = {word[4 * e], word[4 * e + 1], word[4 * e + 2], word[4 * e + 3]};
       stream_store(w4, reinterpret_cast<u32x4*>(obase + (size_t)ooff + (size_t)(16 * T * e)));
     }
-#ifndef RSP_NO_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
+    wave_prio(0);
   }
   if (!kCountPath && fcount) {
     uint32_t any = 0;

@@ -158,15 +158,10 @@ __device__ __forceinline__ void front_end(const void* __restrict__ in, uint32_t 
     f32x2 x[16];
     TwAll<M> twb;
     const uint32_t voff = ((live ? frame : 0u) * (uint32_t)N + (uint32_t)elem_index<M, LO, W>(tau, 0)) * 8u;
-#ifndef RSP_NO_PRIO   // a workgroup's frame loads (and, in quad_emit, its word stores) issue ahead of the resident waves'
-                      // arithmetic: 41.2-41.3 -> 40.8-40.9 us at cfg 2 (same-box A/B, three rounds)
-    __builtin_amdgcn_s_setprio(3);
-#endif
+    wave_prio(1);
     fft_f32_load<M>([&](int d) { return stream_load(reinterpret_cast<const f32x2*>(gbase + (size_t)voff + (size_t)d * 8u)); },
                     tau, reinterpret_cast<const f32x2*>(tw), twb, x);
-#ifndef RSP_NO_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
+    wave_prio(0);
     if (rg.window) {  // pre-FFT window (build extension): one fp32 coefficient per sample
       const float* wt = reinterpret_cast<const float*>(rg.window) + elem_index<M, LO, W>(tau, 0);
 #pragma unroll

@@ -222,19 +222,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // us at cfg 4 (same-box A/B, three rounds, against a side build without the hints: -DRSP_NO_NT).
 template <typename T>
 __device__ __forceinline__ T stream_load(const T* p) {
-#ifdef RSP_NO_NT
-  return *p;
-#else
-  return __builtin_nontemporal_load(p);
-#endif
+  if constexpr (kStreamHints) return __builtin_nontemporal_load(p);
+  else return *p;
 }
 template <typename T>
 __device__ __forceinline__ void stream_store(T v, T* p) {
-#ifdef RSP_NO_NT
-  *p = v;
-#else
-  __builtin_nontemporal_store(v, p);
-#endif
+  if constexpr (kStreamHints) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+// a workgroup's frame loads / word stores issue ahead of the resident waves' arithmetic: 41.2-41.3 -> 40.8-40.9 us at
+// cfg 2 (same-box A/B, three rounds)
+__device__ __forceinline__ void wave_prio(int p) {
+  if constexpr (kWavePrio) {
+    if (p) __builtin_amdgcn_s_setprio(3);
+    else __builtin_amdgcn_s_setprio(0);
+  }
 }
 
 
@@ -395,11 +397,7 @@ __device__ __forceinline__ void fft_f32_exchange(int tau, f32x2* buf, const TwAl
   Hooks::barrier();
   hk.template after_exchange_barrier<P>();
   if (!hk.off(3)) {
-#ifdef RSP_EXCHANGE_READ2   // (side builds) the compiler's pairing, for A/B runs
-    if constexpr (false) {
-#else
-    if constexpr (lds_read_max_off<M, LO1, W1>() < 65536) {
-#endif
+    if constexpr (kExchangeB64 && lds_read_max_off<M, LO1, W1>() < 65536) {
       lds_read8_b64<M, LO1, W1, LAST, 0>(tau, buf, x);
       lds_read8_b64<M, LO1, W1, LAST, 1>(tau, buf, x);
     } else {

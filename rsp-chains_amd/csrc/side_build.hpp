@@ -67,4 +67,21 @@ constexpr bool kCountPath = true;
 constexpr bool kCountPath = false;
 #endif
 
+// A/B switches of kept optimisations (tools/build_variant.sh x.so -DRSP_NO_NT ...): the product builds with all three on
+#ifdef RSP_NO_NT
+constexpr bool kStreamHints = false;   // non-temporal frame loads / word stores
+#else
+constexpr bool kStreamHints = true;
+#endif
+#ifdef RSP_NO_PRIO
+constexpr bool kWavePrio = false;      // s_setprio around a workgroup's frame loads and word stores
+#else
+constexpr bool kWavePrio = true;
+#endif
+#ifdef RSP_EXCHANGE_READ2
+constexpr bool kExchangeB64 = false;   // FFT exchange reads as ds_read_b64 (asm) instead of the compiler's ds_read2_b64 pairing
+#else
+constexpr bool kExchangeB64 = true;
+#endif
+
 }  // namespace rsp
