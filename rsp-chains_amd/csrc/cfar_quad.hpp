@@ -136,15 +136,16 @@ __device__ __forceinline__ void quad_emit(const QuadWords word, const QuadCuts<V
       uint32_t hits = 0;
 #pragma unroll
       for (int j = 0; j < 16; ++j) hits |= (word[j] & 1u) << j;
+      uint32_t slot = atomicAdd(det_cnt, (uint32_t)__popc(hits));  // one LDS atomic per thread, not per peak (dense scenes)
       while (hits) {
         const int j = __ffs(hits) - 1;
         hits &= hits - 1;
         uint32_t w = word[0];
 #pragma unroll
         for (int q = 1; q < 16; ++q) w = (j == q) ? word[q] : w;
-        const uint32_t slot = atomicAdd(det_cnt, 1u);
         if (slot < (uint32_t)kFrameDetCap)
           det_stage[slot] = make_uint2((uint32_t)(4 * tau + 4 * T * (j >> 2) + (j & 3)), w);
+        ++slot;
       }
     }
     // per-frame detection slots (no global atomics): count + first kFrameDetCap peaks

@@ -291,14 +291,17 @@ __device__ __forceinline__ void emit_words(const uint32_t (&word)[16], uint32_t*
     uint32_t hits = 0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) hits |= (word[j] & 1u) << j;
-    while (hits) {  // rare: ~1 peak per 1000 cells
-      const int j = __ffs(hits) - 1;
-      hits &= hits - 1;
-      uint32_t w = word[0];
+    if (hits) {  // rare: ~1 peak per 1000 cells; one LDS atomic per thread with peaks
+      uint32_t slot = atomicAdd(det_cnt, (uint32_t)__popc(hits));
+      while (hits) {
+        const int j = __ffs(hits) - 1;
+        hits &= hits - 1;
+        uint32_t w = word[0];
 #pragma unroll
-      for (int q = 1; q < 16; ++q) w = (j == q) ? word[q] : w;
-      const uint32_t slot = atomicAdd(det_cnt, 1u);
-      if (slot < (uint32_t)kFrameDetCap) det_stage[slot] = make_uint2((uint32_t)(tau + T * j), w);
+        for (int q = 1; q < 16; ++q) w = (j == q) ? word[q] : w;
+        if (slot < (uint32_t)kFrameDetCap) det_stage[slot] = make_uint2((uint32_t)(tau + T * j), w);
+        ++slot;
+      }
     }
     // per-frame detection slots (no global atomics): count + first kFrameDetCap peaks
     __syncthreads();
