@@ -196,6 +196,7 @@ def test_detection_list_is_complete_beyond_the_per_frame_staging(gpu):
         assert cnt[0] == fr.size and cnt[1] == fr.size
         lst = d_list.download(np.uint32, int(cnt[1]) * 4).reshape(-1, 4)
         assert sorted((int(a), int(b), int(w)) for a, b, _, w in lst) == want
+        assert np.array_equal(lst[:, 0], fr)          # frames in ascending order, the overflowing ones (helper workgroups) too
         dut.process_detect_device(d_in.ptr, frames, 0, d_list.ptr, cap, d_cnt.ptr)   # list only
         dut.synchronize()
         cnt = d_cnt.download(np.uint32, 2)
