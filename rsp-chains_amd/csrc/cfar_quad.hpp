@@ -51,7 +51,10 @@ struct QuadLds {
 // the geometry the quad tail is built for (host-side dispatch, launch_m)
 __host__ __device__ inline bool quad_tail_supports(int log2n, const ChainRegs& rg) {
   (void)log2n;
-  return rg.algorithm == 0 && rg.cfar_mode <= 2 && (rg.R & 3) == 0 && (rg.G & 3) == 0 && rg.R + rg.G + 4 <= kQHalo;
+  // guardWindowSize a multiple of 4: every window edge of a quad's four cells is one aligned 16-byte LDS read; 2 mod 4
+  // (round 3: the reference's run-time guard goes 1 .. 4): the edges are 8-byte aligned, two 8-byte reads, and a quad's
+  // halves may sit in different prefix blocks (the G2 instantiations of the cell stage)
+  return rg.algorithm == 0 && rg.cfar_mode <= 2 && (rg.R & 3) == 0 && (rg.G & 1) == 0 && rg.R + rg.G + 4 <= kQHalo;
 }
 
 template <int CTRL, int RMASK, bool BOUND, typename V>
@@ -354,36 +357,57 @@ __device__ __forceinline__ void quad_tail(unsigned char* fbase, const V (&mg)[16
     // block (256 cells; 16 with SHORTW) of the two window starts, and whether the window ends in the next block: then
     // the start block's total is added.  A quad never straddles a block, so this is per quad; the
     // "no" case reads the slot that holds 0, which keeps the read unconditional (no divergent branch).
-    auto cells = [&](auto mode_c, auto group_c) {
+    auto cells = [&](auto mode_c, auto group_c, auto g2_c) {
       constexpr int MODE = decltype(mode_c)::value;
       constexpr bool GROUP = decltype(group_c)::value;
-      int i0[4], i1[4];
-      if constexpr ((4 * T) % (1 << BSH) == 0) {  // a thread's quads sit whole blocks apart: same case for all four
-        const int bu0 = (k00 - G - R) >> BSH, bu1 = (k00 + G) >> BSH;
-        const bool z0 = ((k00 - G) >> BSH) == bu0, z1 = ((k00 + G + R) >> BSH) == bu1;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          i0[e] = z0 ? ZS : bu0 + ((4 * T) >> BSH) * e;
-          i1[e] = z1 ? ZS : bu1 + ((4 * T) >> BSH) * e;
+      // G2: guardWindowSize = 2 mod 4.  The window edges of a quad's cells start two cells off quad alignment: 8-byte
+      // reads, and cells 0,1 / 2,3 of the quad (NH = 2 halves) have their own prefix blocks and fix-ups.
+      constexpr bool G2 = decltype(g2_c)::value;
+      constexpr int NH = G2 ? 2 : 1;
+      typedef V V2 __attribute__((ext_vector_type(2)));
+      auto ld4 = [](const V* p) -> V4 {
+        if constexpr (G2) {
+          const V2 lo = *reinterpret_cast<const V2*>(p), hi = *reinterpret_cast<const V2*>(p + 2);
+          return V4{lo[0], lo[1], hi[0], hi[1]};
+        } else {
+          return *reinterpret_cast<const V4*>(p);
         }
-      } else {
+      };
+      int i0[4][NH], i1[4][NH];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int k0 = k00 + 4 * T * e;
-          const int bu0 = (k0 - G - R) >> BSH, bu1 = (k0 + G) >> BSH;
-          i0[e] = ((k0 - G) >> BSH) != bu0 ? bu0 : ZS;
-          i1[e] = ((k0 + G + R) >> BSH) != bu1 ? bu1 : ZS;
+      for (int h = 0; h < NH; ++h) {
+        const int kh = k00 + 2 * h;  // first cell of the half
+        if constexpr ((4 * T) % (1 << BSH) == 0) {  // a thread's quads sit whole blocks apart: same case for all four
+          const int bu0 = (kh - G - R) >> BSH, bu1 = (kh + G) >> BSH;
+          const bool z0 = ((kh - G) >> BSH) == bu0, z1 = ((kh + G + R) >> BSH) == bu1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            i0[e][h] = z0 ? ZS : bu0 + ((4 * T) >> BSH) * e;
+            i1[e][h] = z1 ? ZS : bu1 + ((4 * T) >> BSH) * e;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int k0 = kh + 4 * T * e;
+            const int bu0 = (k0 - G - R) >> BSH, bu1 = (k0 + G) >> BSH;
+            i0[e][h] = ((k0 - G) >> BSH) != bu0 ? bu0 : ZS;
+            i1[e][h] = ((k0 + G + R) >> BSH) != bu1 ? bu1 : ZS;
+          }
         }
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int k0 = k00 + 4 * T * e;
-        const V4 Pa = *reinterpret_cast<const V4*>(pa + ES * e), Pb = *reinterpret_cast<const V4*>(pbq + ES * e);
-        const V4 Pe = *reinterpret_cast<const V4*>(pe + ES * e), Ps = *reinterpret_cast<const V4*>(ps + ES * e);
-        const V4 Me = *reinterpret_cast<const V4*>(me + ES * e), Ms = *reinterpret_cast<const V4*>(ms + ES * e);
+        const V4 Pa = ld4(pa + ES * e), Pb = ld4(pbq + ES * e);
+        const V4 Pe = ld4(pe + ES * e), Ps = ld4(ps + ES * e);
+        const V4 Me = ld4(me + ES * e), Ms = ld4(ms + ES * e);
         // (kSerialQuads: the quad's own magnitudes are read again instead of being carried from the scan in registers)
         const V4 cut = Hooks::kSerialQuads ? *reinterpret_cast<const V4*>(mc + ES * e) : mq[e];
-        const V f0 = bs[i0[e]], f1 = bs[i1[e]];
+        V f0h[2], f1h[2];  // block fix-ups of the quad's two halves (equal unless G2)
+        f0h[0] = bs[i0[e][0]];
+        f1h[0] = bs[i1[e][0]];
+        f0h[1] = G2 ? bs[i0[e][NH - 1]] : f0h[0];
+        f1h[1] = G2 ? bs[i1[e][NH - 1]] : f1h[0];
         V nl = V(0), nr = V(0);
         if constexpr (GROUP) {
           nl = mc[ES * e - 1];
@@ -392,9 +416,10 @@ __device__ __forceinline__ void quad_tail(unsigned char* fbase, const V (&mg)[16
         if constexpr (!FIXED) {
           // two cells per packed op: sums, combination and threshold of a quad in 14-16 v_pk ops
           const f32x2 kAA = {MODE == 0 ? kA * 0.5f : kA, MODE == 0 ? kA * 0.5f : kA}, kBB = {kB, kB};
-          const f32x2 f00 = {f0, f0}, f11 = {f1, f1}, f01 = {f0 + f1, f0 + f1};
           auto half = [&](auto hc) {
             constexpr int h = decltype(hc)::value;
+            const float f0 = f0h[h], f1 = f1h[h];
+            const f32x2 f00 = {f0, f0}, f11 = {f1, f1}, f01 = {f0 + f1, f0 + f1};
             const f32x2 a = __builtin_shufflevector(Pa, Pa, 2 * h, 2 * h + 1), b = __builtin_shufflevector(Pb, Pb, 2 * h, 2 * h + 1);
             const f32x2 pe2 = __builtin_shufflevector(Pe, Pe, 2 * h, 2 * h + 1), ps2 = __builtin_shufflevector(Ps, Ps, 2 * h, 2 * h + 1);
             const f32x2 me2 = __builtin_shufflevector(Me, Me, 2 * h, 2 * h + 1), ms2 = __builtin_shufflevector(Ms, Ms, 2 * h, 2 * h + 1);
@@ -430,8 +455,8 @@ __device__ __forceinline__ void quad_tail(unsigned char* fbase, const V (&mg)[16
           half(std::integral_constant<int, 0>{});
           half(std::integral_constant<int, 1>{});
         } else {
-          const V4 lag = (Pa - Pb) + f0;
-          const V4 lead = ((Pe - Ps) + (Me - Ms)) + f1;
+          const V4 lag = (Pa - Pb) + V4{f0h[0], f0h[0], f0h[1], f0h[1]};
+          const V4 lead = ((Pe - Ps) + (Me - Ms)) + V4{f1h[0], f1h[0], f1h[1], f1h[1]};
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             bool group_ok = true;
@@ -457,16 +482,22 @@ __device__ __forceinline__ void quad_tail(unsigned char* fbase, const V (&mg)[16
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
+    auto by_mode = [&](auto group_c, auto g2_c) {
+      if (rg.cfar_mode == 0) cells(I0{}, group_c, g2_c);
+      else if (rg.cfar_mode == 1) cells(I1{}, group_c, g2_c);
+      else cells(I2{}, group_c, g2_c);
+    };
+    const bool g2 = (G & 3) == 2;
     if constexpr (kCountPath) {  // static instruction counts of ONE path (tools/count_insts.sh): CA, no grouping
-      cells(I0{}, std::false_type{});
-    } else if (!Hooks::kSerialQuads && rg.peak_grouping) {  // (the pipelined experiment leaves peak grouping to the plain kernel)
-      if (rg.cfar_mode == 0) cells(I0{}, std::true_type{});
-      else if (rg.cfar_mode == 1) cells(I1{}, std::true_type{});
-      else cells(I2{}, std::true_type{});
+      cells(I0{}, std::false_type{}, std::false_type{});
+    } else if constexpr (Hooks::kSerialQuads) {  // (the pipelined experiment: aligned guards, no peak grouping)
+      by_mode(std::false_type{}, std::false_type{});
+    } else if (rg.peak_grouping) {
+      if (g2) by_mode(std::true_type{}, std::true_type{});
+      else by_mode(std::true_type{}, std::false_type{});
     } else {
-      if (rg.cfar_mode == 0) cells(I0{}, std::false_type{});
-      else if (rg.cfar_mode == 1) cells(I1{}, std::false_type{});
-      else cells(I2{}, std::false_type{});
+      if (g2) by_mode(std::false_type{}, std::true_type{});
+      else by_mode(std::false_type{}, std::false_type{});
     }
   }
 

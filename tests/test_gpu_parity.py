@@ -508,3 +508,29 @@ def test_gos_short_frames_wide_guards(gpu, n, ref, guard, idx):
         words = dut.stream(x)
     thr, peak, margin, mag = O.chain_f32(x, oracle_fcfg(pf, rt), want_mag=True)
     compare_f32(words, thr, peak, margin, mag)
+
+
+@pytest.mark.parametrize("n,ref,guard", [(256, 8, 2), (1024, 16, 6), (1024, 32, 2), (4096, 32, 10), (4096, 64, 2), (8192, 16, 2), (512, 4, 2)])
+@pytest.mark.parametrize("mode,edge,grouping", [("Cell Averaging", "zero", 0), ("Greatest Of", "wrap", 1), ("Smallest Of", "zero", 1)])
+def test_quad_tail_even_guards(gpu, n, ref, guard, mode, edge, grouping):
+    """guardWindowSize = 2 mod 4 on the quad tail (8-byte window-edge reads, per-half prefix blocks): FIXED16 bit-exact
+    against the oracle AND identical to the per-cell tail's words; fp32 in the common tolerance (16-cell-block prefixes
+    for the windows of at most 16 cells)."""
+    params = make_params(n, guard=16, edge=edge)
+    rt = R.RunTimeRspChainParams(fftSize=n, CFARMode=mode, refWindowSize=ref, guardWindowSize=guard,
+                                 divSum=int(np.log2(ref)), thresholdScaler=2.0, peakGrouping=grouping)
+    beats = np.concatenate([tone_beats(2, n, 12 + n + guard), random_beats(7, n, n + ref)])
+    oracle = O.chain_fixed(beats, oracle_cfg(params, rt)).reshape(len(beats), n)
+    with R.FftMagCfarChainVanilla(params) as dut:
+        dut.configure(rt)
+        got = dut.stream(beats)
+        dut.set_option(dut.FORCE_GENERIC_TAIL, 1)
+        per_cell = dut.stream(beats)
+    assert np.array_equal(got, oracle) and np.array_equal(per_cell, oracle)
+    pf = make_params(n, dtype=R.F32, guard=16, edge=edge)
+    x = R.stimulus.chirp_frames(5, n, seed=guard + n)
+    with R.FftMagCfarChainVanilla(pf) as dut:
+        dut.configure(rt)
+        words = dut.stream(x)
+    thr, peak, margin, mag = O.chain_f32(x, oracle_fcfg(pf, rt), want_mag=True)
+    compare_f32(words, thr, peak, margin, mag)
